@@ -1,0 +1,143 @@
+"""Oracle: HRNet (UDP variant) forward on CPU (TEST INFRASTRUCTURE ONLY).
+
+Functional restatement of deep_hrnet/lib/models/pose_hrnet.py driven directly
+by a reference-format ``state_dict`` and the ``MODEL.EXTRA`` dict of the YAML:
+  forward                        :436-471
+  Bottleneck / BasicBlock        :62-100 / :29-59
+  HighResolutionModule.forward   :260-273, fuse layers :189-255
+  transitions                    :344-383
+Stock torch.nn.functional ops in fp32 (conv2d, batch_norm(eval), relu,
+interpolate(nearest)).  Pinned against the reference module itself on the same
+weights and inputs (tests/golden/hrnet_*.npz, oracle/gen_golden.py).
+
+``calibrate=True`` runs every BatchNorm on batch statistics and writes them
+back into ``sd`` as running_mean / running_var (used once, in the build
+container, to give synthetic weights realistic statistics).
+"""
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-5
+
+
+class _Net:
+    def __init__(self, sd, calibrate=False):
+        self.sd = sd
+        self.calibrate = calibrate
+
+    def conv(self, x, name, stride=1, pad=None):
+        w = self.sd[name + ".weight"]
+        if pad is None:
+            pad = (w.shape[2] - 1) // 2
+        return F.conv2d(x, w, self.sd.get(name + ".bias"), stride=stride, padding=pad)
+
+    def bn(self, x, name):
+        if self.calibrate:
+            mean = x.mean(dim=(0, 2, 3))
+            var = x.var(dim=(0, 2, 3), unbiased=False)
+            self.sd[name + ".running_mean"] = mean.clone()
+            self.sd[name + ".running_var"] = var.clone()
+        return F.batch_norm(x, self.sd[name + ".running_mean"], self.sd[name + ".running_var"],
+                            self.sd[name + ".weight"], self.sd[name + ".bias"],
+                            training=False, eps=BN_EPS)
+
+    def has(self, name):
+        return (name + ".weight") in self.sd
+
+
+def _basic_block(net, x, p):
+    out = F.relu(net.bn(net.conv(x, p + ".conv1"), p + ".bn1"))
+    out = net.bn(net.conv(out, p + ".conv2"), p + ".bn2")
+    return F.relu(out + x)
+
+
+def _bottleneck(net, x, p):
+    out = F.relu(net.bn(net.conv(x, p + ".conv1"), p + ".bn1"))
+    out = F.relu(net.bn(net.conv(out, p + ".conv2"), p + ".bn2"))
+    out = net.bn(net.conv(out, p + ".conv3"), p + ".bn3")
+    res = x
+    if net.has(p + ".downsample.0"):
+        res = net.bn(net.conv(x, p + ".downsample.0"), p + ".downsample.1")
+    return F.relu(out + res)
+
+
+def _fuse_term(net, xj, p, i, j, last_module):
+    """f_ij of pose_hrnet.py:198-252."""
+    q = "%s.fuse_layers.%d.%d" % (p, i, j)
+    if j > i:
+        y = net.bn(net.conv(xj, q + ".0"), q + ".1")
+        return F.interpolate(y, scale_factor=2 ** (j - i), mode="nearest")
+    if j == i:
+        if last_module:
+            return net.conv(xj, q + ".0")          # 1x1 C -> 4C, no BN (:214-221)
+        return xj
+    y = xj
+    for k in range(i - j):
+        y = net.bn(net.conv(y, "%s.%d.0" % (q, k), stride=2), "%s.%d.1" % (q, k))
+        if k != i - j - 1:
+            y = F.relu(y)
+    return y
+
+
+def _hr_module(net, xs, p, num_blocks, last_module):
+    nb = len(xs)
+    xs = list(xs)
+    for b in range(nb):
+        for k in range(num_blocks[b]):
+            xs[b] = _basic_block(net, xs[b], "%s.branches.%d.%d" % (p, b, k))
+    n_out = 1 if last_module else nb
+    outs = []
+    for i in range(n_out):
+        y = _fuse_term(net, xs[0], p, i, 0, last_module)
+        for j in range(1, nb):
+            y = y + _fuse_term(net, xs[j], p, i, j, last_module)
+        outs.append(F.relu(y))
+    return outs
+
+
+def _transition(net, ys, name, n_cur):
+    n_pre = len(ys)
+    xs = []
+    for i in range(n_cur):
+        q = "%s.%d" % (name, i)
+        if i < n_pre:
+            if net.has(q + ".0"):
+                xs.append(F.relu(net.bn(net.conv(ys[i], q + ".0"), q + ".1")))
+            else:
+                xs.append(ys[i])
+        else:
+            y = ys[-1]
+            for k in range(i + 1 - n_pre):
+                y = F.relu(net.bn(net.conv(y, "%s.%d.0" % (q, k), stride=2), "%s.%d.1" % (q, k)))
+            xs.append(y)
+    return xs
+
+
+@torch.no_grad()
+def hrnet_forward(sd, extra, x, calibrate=False, taps=None):
+    """pose_hrnet.py:436-471.  ``sd``: reference state_dict (fp32 tensors),
+    ``extra``: MODEL.EXTRA dict, ``x``: [N,3,H,W] fp32.  Optional ``taps``
+    dict receives named intermediate activations."""
+    net = _Net(sd, calibrate)
+    x = F.relu(net.bn(net.conv(x, "conv1", stride=2), "bn1"))
+    x = F.relu(net.bn(net.conv(x, "conv2", stride=2), "bn2"))
+    if taps is not None:
+        taps["stem"] = x
+    for k in range(4):
+        x = _bottleneck(net, x, "layer1.%d" % k)
+    if taps is not None:
+        taps["layer1"] = x
+    ys = [x]
+    for s, tname in ((2, "transition1"), (3, "transition2"), (4, "transition3")):
+        cfg = extra["STAGE%d" % s]
+        assert cfg["BLOCK"] == "BASIC" and cfg["FUSE_METHOD"] == "SUM"
+        xs = _transition(net, ys, tname, cfg["NUM_BRANCHES"])
+        for m in range(cfg["NUM_MODULES"]):
+            last = (s == 4 and m == cfg["NUM_MODULES"] - 1)
+            xs = _hr_module(net, xs, "stage%d.%d" % (s, m), cfg["NUM_BLOCKS"], last)
+        ys = xs
+        if taps is not None:
+            for b, y in enumerate(ys):
+                taps["stage%d.%d" % (s, b)] = y
+    pad = 1 if extra.get("FINAL_CONV_KERNEL", 1) == 3 else 0
+    return net.conv(ys[0], "final_layer", pad=pad)

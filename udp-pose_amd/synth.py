@@ -1,0 +1,259 @@
+"""Synthetic HRNet weights in the reference's state_dict format.
+
+No pretrained weights ship with the reference, so parity tests
+and the benchmark use seeded random weights.  ``hrnet_param_shapes`` enumerates
+the weight-file contract of deep_hrnet/lib/models/pose_hrnet.py (key names and
+shapes of ``PoseHighResolutionNet.state_dict()``, :282-342 / :189-255 /
+:344-383); ``synth_state_dict`` fills it from a NumPy PCG64 stream, so the same
+(seed, config) gives the same weights in the build container and on the GPU
+box.  BatchNorm running statistics may be overlaid from a calibration fixture
+(tests/golden/bn_calib_*.npz, written in the build container by
+oracle/gen_golden.py) so that activations keep a realistic O(1) scale through
+all ~60 sequential layers.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+
+def _bn(shapes, name, c):
+    shapes[name + ".weight"] = (c,)
+    shapes[name + ".bias"] = (c,)
+    shapes[name + ".running_mean"] = (c,)
+    shapes[name + ".running_var"] = (c,)
+    shapes[name + ".num_batches_tracked"] = ()
+
+
+def hrnet_param_shapes(extra, num_joints=17, target_type="gaussian"):
+    """Ordered {key: shape} of the reference PoseHighResolutionNet state_dict."""
+    s = OrderedDict()
+    s["conv1.weight"] = (64, 3, 3, 3)
+    _bn(s, "bn1", 64)
+    s["conv2.weight"] = (64, 64, 3, 3)
+    _bn(s, "bn2", 64)
+    inpl = 64
+    for k in range(4):                                   # layer1: 4 Bottlenecks, planes 64
+        p = "layer1.%d" % k
+        s[p + ".conv1.weight"] = (64, inpl, 1, 1)
+        _bn(s, p + ".bn1", 64)
+        s[p + ".conv2.weight"] = (64, 64, 3, 3)
+        _bn(s, p + ".bn2", 64)
+        s[p + ".conv3.weight"] = (256, 64, 1, 1)
+        _bn(s, p + ".bn3", 256)
+        if k == 0:
+            s[p + ".downsample.0.weight"] = (256, inpl, 1, 1)
+            _bn(s, p + ".downsample.1", 256)
+        inpl = 256
+    pre = [256]
+    for st in (2, 3, 4):
+        cfg = extra["STAGE%d" % st]
+        if cfg["BLOCK"] != "BASIC":
+            raise ValueError("only BASIC blocks are supported in stages 2-4")
+        chans = list(cfg["NUM_CHANNELS"])
+        nb = cfg["NUM_BRANCHES"]
+        if nb != len(chans) or nb != len(cfg["NUM_BLOCKS"]):
+            raise ValueError("NUM_BRANCHES(%d) <> NUM_CHANNELS/NUM_BLOCKS" % nb)
+        t = "transition%d" % (st - 1)
+        for i in range(nb):
+            if i < len(pre):
+                if chans[i] != pre[i]:
+                    s["%s.%d.0.weight" % (t, i)] = (chans[i], pre[i], 3, 3)
+                    _bn(s, "%s.%d.1" % (t, i), chans[i])
+            else:
+                for k in range(i + 1 - len(pre)):
+                    cin = pre[-1]
+                    cout = chans[i] if k == i - len(pre) else cin
+                    s["%s.%d.%d.0.weight" % (t, i, k)] = (cout, cin, 3, 3)
+                    _bn(s, "%s.%d.%d.1" % (t, i, k), cout)
+        nmod = cfg["NUM_MODULES"]
+        for m in range(nmod):
+            last = (st == 4 and m == nmod - 1)
+            p = "stage%d.%d" % (st, m)
+            for b in range(nb):
+                for k in range(cfg["NUM_BLOCKS"][b]):
+                    q = "%s.branches.%d.%d" % (p, b, k)
+                    s[q + ".conv1.weight"] = (chans[b], chans[b], 3, 3)
+                    _bn(s, q + ".bn1", chans[b])
+                    s[q + ".conv2.weight"] = (chans[b], chans[b], 3, 3)
+                    _bn(s, q + ".bn2", chans[b])
+            inch = list(chans)
+            if last:
+                inch[0] *= 4
+            for i in range(1 if last else nb):
+                for j in range(nb):
+                    q = "%s.fuse_layers.%d.%d" % (p, i, j)
+                    if j > i:
+                        s[q + ".0.weight"] = (inch[i], inch[j], 1, 1)
+                        _bn(s, q + ".1", inch[i])
+                    elif j == i:
+                        if last:
+                            s[q + ".0.weight"] = (inch[j], inch[j] // 4, 1, 1)
+                    else:
+                        for k in range(i - j):
+                            cout = inch[i] if k == i - j - 1 else inch[j]
+                            s["%s.%d.0.weight" % (q, k)] = (cout, inch[j], 3, 3)
+                            _bn(s, "%s.%d.1" % (q, k), cout)
+            if last:
+                chans = inch
+        pre = chans
+    factor = 3 if target_type == "offset" else 1
+    fk = int(extra.get("FINAL_CONV_KERNEL", 1))
+    s["final_layer.weight"] = (num_joints * factor, pre[0], fk, fk)
+    s["final_layer.bias"] = (num_joints * factor,)
+    return s
+
+
+def synth_state_dict(extra, num_joints=17, target_type="gaussian", seed=0, bn_calib=None):
+    """Seeded synthetic state_dict (fp32 torch tensors, CPU).
+
+    conv ~ N(0, 2/fan_in); BN gamma ~ U(0.6,1.2) (0.25..0.5 for the closing BN of
+    a residual branch and for fuse BNs, so the residual stream does not blow
+    up), beta ~ N(0,0.05); running stats (0,1) unless ``bn_calib`` (dict of
+    name -> array) overlays calibrated ones.
+    """
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd = OrderedDict()
+    for name, shape in hrnet_param_shapes(extra, num_joints, target_type).items():
+        if name.endswith("num_batches_tracked"):
+            sd[name] = torch.tensor(0, dtype=torch.long)
+            continue
+        if name.endswith("running_mean"):
+            a = np.zeros(shape, np.float32)
+        elif name.endswith("running_var"):
+            a = np.ones(shape, np.float32)
+        elif len(shape) == 4:
+            fan_in = shape[1] * shape[2] * shape[3]
+            a = rng.standard_normal(shape).astype(np.float32) * np.float32(np.sqrt(2.0 / fan_in))
+        elif name == "final_layer.bias":
+            a = (rng.standard_normal(shape) * 0.05).astype(np.float32)
+        elif name.endswith(".weight"):
+            closing = (".bn2." in name + "." and "branches" in name) or ".bn3" in name \
+                or "fuse_layers" in name or "downsample" in name
+            lo, hi = (0.25, 0.5) if closing else (0.6, 1.2)
+            a = rng.uniform(lo, hi, shape).astype(np.float32)
+        else:
+            a = (rng.standard_normal(shape) * 0.05).astype(np.float32)
+        sd[name] = torch.from_numpy(a)
+    if bn_calib is not None:
+        for k, v in bn_calib.items():
+            if k in sd:
+                sd[k] = torch.from_numpy(np.asarray(v, dtype=np.float32).copy())
+        if "final_layer.scale" in bn_calib:          # brings heat-maps to O(1) like trained ones
+            f = float(np.asarray(bn_calib["final_layer.scale"]))
+            sd["final_layer.weight"] = sd["final_layer.weight"] * f
+            sd["final_layer.bias"] = sd["final_layer.bias"] * f
+    return sd
+
+
+W32_EXTRA = {
+    "FINAL_CONV_KERNEL": 1,
+    "PRETRAINED_LAYERS": ["*"],
+    "STAGE2": {"NUM_MODULES": 1, "NUM_BRANCHES": 2, "BLOCK": "BASIC", "NUM_BLOCKS": [4, 4],
+               "NUM_CHANNELS": [32, 64], "FUSE_METHOD": "SUM"},
+    "STAGE3": {"NUM_MODULES": 4, "NUM_BRANCHES": 3, "BLOCK": "BASIC", "NUM_BLOCKS": [4, 4, 4],
+               "NUM_CHANNELS": [32, 64, 128], "FUSE_METHOD": "SUM"},
+    "STAGE4": {"NUM_MODULES": 3, "NUM_BRANCHES": 4, "BLOCK": "BASIC", "NUM_BLOCKS": [4, 4, 4, 4],
+               "NUM_CHANNELS": [32, 64, 128, 256], "FUSE_METHOD": "SUM"},
+}
+
+
+def scaled_extra(width, modules=(1, 4, 3), blocks=4):
+    """HRNet EXTRA dict with branch widths width*(1,2,4,8) (W32: 32, W48: 48;
+    small widths/modules give the mini nets used by the golden fixtures)."""
+    e = {"FINAL_CONV_KERNEL": 1, "PRETRAINED_LAYERS": ["*"]}
+    for i, st in enumerate((2, 3, 4)):
+        nb = st
+        e["STAGE%d" % st] = {
+            "NUM_MODULES": modules[i], "NUM_BRANCHES": nb, "BLOCK": "BASIC",
+            "NUM_BLOCKS": [blocks] * nb, "NUM_CHANNELS": [width * 2 ** b for b in range(nb)],
+            "FUSE_METHOD": "SUM"}
+    return e
+
+
+# ----------------------------------------------------------------------------
+# Synthetic inputs: person crops, boxes, heat-maps.
+# ----------------------------------------------------------------------------
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def synth_frame_u8(h, w, seed=0, blobs=8):
+    """uint8 HxWx3 frame: sum of random Gaussian blobs + uniform noise."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    ys = np.arange(h, dtype=np.float32)[:, None]
+    xs = np.arange(w, dtype=np.float32)[None, :]
+    img = np.zeros((h, w, 3), np.float32)
+    for _ in range(blobs):
+        cy, cx = rng.uniform(0, h), rng.uniform(0, w)
+        s = rng.uniform(0.05, 0.25) * min(h, w)
+        col = rng.uniform(40, 255, 3).astype(np.float32)
+        g = np.exp(-((ys - cy) ** 2 + (xs - cx) ** 2) / (2 * s * s)).astype(np.float32)
+        img += g[:, :, None] * col[None, None, :]
+    img += rng.uniform(0, 30, (h, w, 3)).astype(np.float32)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def synth_crops(n, h=256, w=192, seed=0):
+    """Normalised fp32 crops [N,3,H,W] (ToTensor + ImageNet Normalize of
+    synthetic uint8 patches), as pose_engine.py:40-43 would hand the network."""
+    out = np.empty((n, 3, h, w), np.float32)
+    mean = np.asarray(IMAGENET_MEAN, np.float32)[:, None, None]
+    std = np.asarray(IMAGENET_STD, np.float32)[:, None, None]
+    for i in range(n):
+        u8 = synth_frame_u8(h, w, seed=seed * 100003 + i)
+        x = np.transpose(u8.astype(np.float32) / np.float32(255), (2, 0, 1))
+        out[i] = (x - mean) / std
+    return out
+
+
+def synth_boxes(n, frame_w=640, frame_h=480, seed=0):
+    """xyxy person boxes: centre U([100,540]x[100,380]), w~U(40,200),
+    h = w/0.75*U(0.8,1.2)."""
+    rng = np.random.Generator(np.random.PCG64(seed + 7))
+    cx = rng.uniform(100, frame_w - 100, n)
+    cy = rng.uniform(100, frame_h - 100, n)
+    w = rng.uniform(40, 200, n)
+    h = w / 0.75 * rng.uniform(0.8, 1.2, n)
+    return np.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1).astype(np.float32)
+
+
+def synth_center_scale(n, aspect=0.75, seed=0):
+    """center [N,2] / scale [N,2] (float32) from synth_boxes through the
+    engine's box->center/scale rule (pose_engine.py:55-63)."""
+    b = synth_boxes(n, seed=seed)
+    c = np.stack([(b[:, 0] + b[:, 2]) / 2, (b[:, 1] + b[:, 3]) / 2], 1)
+    w = b[:, 2] - b[:, 0]
+    h = b[:, 3] - b[:, 1]
+    m = w > h * aspect
+    h = np.where(m, w / aspect, h)
+    w = np.where(m, w, h * aspect)
+    s = np.stack([w, h], 1) / 200.0 * 1.25
+    return c.astype(np.float32), s.astype(np.float32)
+
+
+def synth_heatmaps(n, j, h=64, w=48, seed=0, channels_per_joint=1):
+    """Heat-maps [N,J*k,H,W] f32: a sigma=2 Gaussian at a sub-pixel mean,
+    amplitude U(0.3,1), + N(0,0.01^2) noise.  For k=3 (offset head) channels
+    3j+1 / 3j+2 carry the UDP offset field (mu - grid)/4 inside the unit disk
+    plus noise, like JointsDataset.generate_target (offset) would teach."""
+    rng = np.random.Generator(np.random.PCG64(seed + 13))
+    ys = np.arange(h, dtype=np.float32)[:, None]
+    xs = np.arange(w, dtype=np.float32)[None, :]
+    out = np.empty((n, j * channels_per_joint, h, w), np.float32)
+    for a in range(n):
+        for b in range(j):
+            mx, my = rng.uniform(2, w - 3), rng.uniform(2, h - 3)
+            amp = rng.uniform(0.3, 1.0)
+            g = amp * np.exp(-((xs - mx) ** 2 + (ys - my) ** 2) / 8.0)
+            noise = rng.standard_normal((channels_per_joint, h, w)).astype(np.float32) * 0.01
+            if channels_per_joint == 1:
+                out[a, b] = g.astype(np.float32) + noise[0]
+            else:
+                dx = (mx - xs) / 4.0 + 0 * ys
+                dy = (my - ys) / 4.0 + 0 * xs
+                disk = ((dx * dx + dy * dy) <= 1.0).astype(np.float32)
+                out[a, 3 * b] = disk * np.float32(amp) + noise[0]
+                out[a, 3 * b + 1] = (dx * disk).astype(np.float32) + noise[1]
+                out[a, 3 * b + 2] = (dy * disk).astype(np.float32) + noise[2]
+    return out
