@@ -1,0 +1,173 @@
+/*
+ * udp_pose_hip.h -- C ABI of the MI355X-native UDP-Pose hot path (gfx950).
+ *
+ * One shared library (libudp_pose_hip.so), extern "C", plain pointers and sizes,
+ * no torch types.  Every pointer is a DEVICE pointer unless the name ends in
+ * `_host`.  Every entry point returns UDP_OK (0) or a negative error code and
+ * never throws; udp_last_error() gives the message for the calling thread.
+ * The caller owns all buffers; nothing is allocated after udp_hrnet_create().
+ * All work is enqueued on the hipStream_t the caller passes (`stream`, a
+ * hipStream_t cast to void*; NULL = the default stream) and is asynchronous.
+ * A handle is single-stream; distinct handles are independent (one per GPU).
+ *
+ * The reference (realphongha/UDP-Pose) has no FFI layer: its seam is Python
+ * call contracts.  Each entry below names the reference function (file:line
+ * under /root/reference) whose arithmetic it replaces; INTEGRATION.md shows
+ * the ctypes binding a maintainer would add on the reference side.
+ */
+#ifndef UDP_POSE_HIP_H
+#define UDP_POSE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UDP_POSE_ABI_VERSION 1
+
+enum udp_status {
+  UDP_OK = 0,
+  UDP_ERR_ARG = -1,          /* bad argument (null pointer, shape, enum) */
+  UDP_ERR_HIP = -2,          /* a HIP runtime call failed */
+  UDP_ERR_UNSUPPORTED = -3,  /* shape / config outside what the kernels cover */
+  UDP_ERR_WORKSPACE = -4     /* workspace too small */
+};
+
+enum udp_dtype { UDP_F32 = 0, UDP_BF16 = 1 }; /* storage type of activations + weights */
+
+/* ABI version of the loaded library (== UDP_POSE_ABI_VERSION it was built with). */
+int udp_abi_version(void);
+/* Message of the last error on this thread ("" if none). */
+const char* udp_last_error(void);
+
+/* ------------------------------------------------------------------------- *
+ * HRNet forward.  Replaces PoseHighResolutionNet.forward
+ * (deep_hrnet/lib/models/pose_hrnet.py:436-471) incl. BasicBlock :29-59,
+ * Bottleneck :62-100, HighResolutionModule.forward :260-273 with its fuse
+ * layers :189-255 and the transitions :344-383; with flip_test != 0 also the
+ * second forward on the W-mirrored batch of validate()
+ * (deep_hrnet/lib/core/function.py:151-156).
+ *
+ * The network is handed over as a flat program of fused ops (one kernel launch
+ * each) that the host builds from the reference's YAML + state_dict:
+ * BatchNorm (eval) is folded into the conv weights/bias, so an op is
+ *   out = act( conv(in) + bias [+ res] [+ sum_k nearest_up(up_k, 2^shift_k)] ).
+ * Activations are NHWC in `dtype`; buffer b holds buf_elems[b] elements per
+ * image and lives in the caller's workspace.
+ * ------------------------------------------------------------------------- */
+enum udp_op_kind {
+  UDP_OP_STEM = 0, /* 3x3 s2 conv, Cin=3, reads the NCHW fp32 network input    */
+  UDP_OP_CONV = 1, /* implicit-GEMM conv on MFMA, ks 1|3, stride 1|2           */
+  UDP_OP_FUSE = 2  /* no conv: out = act(in + sum_k nearest_up(up_k))          */
+};
+
+#define UDP_BUF_NONE (-1)
+#define UDP_BUF_OUTPUT (-2) /* out_buf: the NCHW fp32 heat-map output of the net */
+
+typedef struct udp_conv_op {
+  int32_t kind;            /* enum udp_op_kind */
+  int32_t ks, stride;      /* kernel size 1|3 (pad = ks/2), stride 1|2 */
+  int32_t relu;            /* apply ReLU in the epilogue */
+  int32_t cin, cout;       /* real channel counts (cin multiple of 32 for UDP_OP_CONV) */
+  int32_t cout_pad;        /* cout rounded up to a multiple of 32: rows of `weights`/`bias` */
+  int32_t hin, win, hout, wout;
+  int32_t in_buf, out_buf, res_buf; /* activation buffer ids; UDP_BUF_NONE / UDP_BUF_OUTPUT */
+  int32_t n_up;            /* 0..3 nearest-upsampled addends */
+  int32_t up_buf[3];
+  int32_t up_shift[3];     /* up_k has (hout>>shift) x (wout>>shift) pixels, cout channels */
+  int64_t w_off;           /* byte offset in the weight blob: [ks*ks][cout_pad][cin] in dtype
+                              (UDP_OP_STEM: fp32 [27][cout]) */
+  int64_t b_off;           /* byte offset of the fp32 bias [cout_pad] */
+} udp_conv_op;
+
+typedef struct udp_hrnet udp_hrnet; /* opaque */
+
+/* weights_dev: device blob (caller-owned, must outlive the handle).  ops and
+ * buf_elems are host arrays, copied.  in_h/in_w: network input size. */
+int udp_hrnet_create(const udp_conv_op* ops_host, int n_ops, const int64_t* buf_elems_host,
+                     int n_bufs, const void* weights_dev, size_t weights_bytes, int dtype,
+                     int in_h, int in_w, int out_channels, udp_hrnet** out);
+/* Bytes of workspace udp_hrnet_forward needs for `n` input images (flip_test doubles it). */
+size_t udp_hrnet_workspace_bytes(const udp_hrnet* h, int n, int flip_test);
+/* in_nchw: fp32 [n,3,in_h,in_w].  heatmaps_nchw: fp32 [n*(flip_test?2:1), C, in_h/4, in_w/4];
+ * with flip_test rows n..2n-1 are the raw outputs for the mirrored inputs (fuse them with
+ * udp_flip_fuse).  use_graph != 0 replays a cached hipGraph of the launch sequence. */
+int udp_hrnet_forward(udp_hrnet* h, const float* in_nchw, int n, int flip_test, void* workspace,
+                      size_t workspace_bytes, float* heatmaps_nchw, int use_graph, void* stream);
+int udp_hrnet_destroy(udp_hrnet* h);
+/* Number of kernel launches of one forward, and algorithmic FLOPs (2*MAC) per image. */
+int udp_hrnet_num_launches(const udp_hrnet* h);
+double udp_hrnet_flops_per_image(const udp_hrnet* h);
+
+/* One fused conv launch on raw pointers (the operator the program above is made of; used by
+ * the per-layer parity tests and kernel benchmarks).  `op` supplies kind (UDP_OP_CONV or
+ * UDP_OP_FUSE), ks, stride, relu, cin, cout, cout_pad, hin, win, hout, wout, n_up, up_shift;
+ * its buffer ids and blob offsets are ignored except out_buf == UDP_BUF_OUTPUT, which selects
+ * the NCHW fp32 output form.  in/res/ups/out: NHWC `dtype`; weights [ks*ks][cout_pad][cin]
+ * `dtype`; bias fp32 [cout_pad].  Replaces conv+BN(+add)(+ReLU), pose_hrnet.py:43-59. */
+int udp_conv2d_fused(const udp_conv_op* op_host, int dtype, int n, const void* in, const void* weights,
+                     const float* bias, const void* res, const void* up0, const void* up1,
+                     const void* up2, void* out, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Flip-test fuse.  Replaces flip_back / flip_back_offset
+ * (deep_hrnet/lib/utils/transforms.py:15-29 / :31-47) and
+ * output = (output + output_flipped) * 0.5 (deep_hrnet/lib/core/function.py:161-171).
+ * out[n,c,y,x] = 0.5f * (a[n,c,y,x] + sign[c] * b[n,src_ch[c],y,w-1-x]).
+ * src_ch / sign: device arrays of length c (channel permutation and +-1).
+ * out may alias a.
+ * ------------------------------------------------------------------------- */
+int udp_flip_fuse(const float* a, const float* b, const int32_t* src_ch, const float* sign,
+                  int n, int c, int h, int w, float* out, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * UDP decode.  Replaces get_final_preds (deep_hrnet/lib/core/inference.py:149-186):
+ * get_max_preds :30-58, post (DARK/Taylor) :60-145, the offset branch :156-174 and
+ * transform_preds :20-27.  heatmaps: fp32 [n, j*(offset?3:1), h, w] (not modified).
+ * center, scale: fp64 [n,2]; cs_is_f32 != 0 says the caller's arrays were float32
+ * (the reference then rounds scale*200, scale/(w-1) and scale*0.5 to fp32).
+ * Outputs: preds fp64 [n,j,2] (image pixels), maxvals fp32 [n,j], preds_in fp64
+ * [n,j,2] (preds_in_input_space), argidx int32 [n,j] (flat arg-max index; may be NULL).
+ * ------------------------------------------------------------------------- */
+int udp_decode_gaussian(const float* heatmaps, int n, int j, int h, int w, const double* center,
+                        const double* scale, int cs_is_f32, int post_process, double* preds,
+                        float* maxvals, double* preds_in, int32_t* argidx, void* stream);
+int udp_decode_offset(const float* heatmaps, int n, int j, int h, int w, const double* center,
+                      const double* scale, int cs_is_f32, float kpd, double* preds, float* maxvals,
+                      double* preds_in, int32_t* argidx, void* stream);
+/* Host helper: the 1-D Gaussian taps cv2.GaussianBlur(ksize, sigma=0) uses (fp32). */
+int udp_gaussian_taps_host(int ksize, float* taps_host);
+
+/* ------------------------------------------------------------------------- *
+ * UDP data path.
+ * udp_warp_affine: cv2.warpAffine(INTER_LINEAR, constant-0 border) on a uint8
+ * HxWx3 frame + ToTensor + Normalize, one 2x3 dst->src matrix per crop
+ * (deep_hrnet/pose_engine.py:69-85,40-43 with the inverse of
+ * tools/infer_utils/utils.py:157-177; deep_hrnet/lib/dataset/JointsDataset.py:226-227
+ * with get_warpmatrix :29-49).  mats: fp64 [n,6] dst->src.  out: fp32 [n,3,oh,ow].
+ * ------------------------------------------------------------------------- */
+int udp_warp_affine(const uint8_t* frame, int fh, int fw, int row_stride_bytes, const double* mats,
+                    int n, int oh, int ow, const float* mean3, const float* std3, float* out,
+                    void* stream);
+/* generate_target (JointsDataset.py:291-385).  joints fp32 [n,j,2] in crop pixels,
+ * vis fp32 [n,j].  gaussian: target [n,j,h,w]; offset: [n,3j,h,w].  weight [n,j]. */
+int udp_target_gaussian(const float* joints, const float* vis, int n, int j, int img_w, int img_h,
+                        int hm_w, int hm_h, float sigma, float* target, float* weight, void* stream);
+int udp_target_offset(const float* joints, const float* vis, int n, int j, int img_w, int img_h,
+                      int hm_w, int hm_h, float kpd, float* target, float* weight, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * JointsMSELoss / JointsMSELoss_offset forward + gradient
+ * (deep_hrnet/lib/core/loss.py:15-39 / :41-76).  pred, target: fp32 [b,c,hw];
+ * weight fp32 [b,j].  loss_out: fp64 [2] = (L_hm, L_offset) (L_offset = 0 for the
+ * plain loss); grad: fp32 like pred (d(L_hm+L_offset)/d pred), may be NULL.
+ * ------------------------------------------------------------------------- */
+int udp_mse_loss(const float* pred, const float* target, const float* weight, int b, int j, int hw,
+                 int is_offset, double* loss_out, float* grad, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UDP_POSE_HIP_H */

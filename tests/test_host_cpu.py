@@ -1,0 +1,92 @@
+"""CPU-side checks of the product: the C-ABI library loads and exports every symbol the
+header declares, argument validation works without a GPU, and the host compiler
+(HRNetProgram) reproduces the reference graph's census."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from udp_pose_amd import _lib, hrnet_plan, synth
+from udp_pose_amd.config import load_config
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "udp_pose_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(udp_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no prototypes parsed"
+    lib = _lib.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libudp_pose_hip.so does not export %s" % name
+    assert declared == set(_lib.EXPORTS)
+    assert lib.udp_abi_version() == 1
+
+
+def test_argument_validation_without_gpu():
+    lib = _lib.lib()
+    assert lib.udp_decode_gaussian(None, 1, 17, 64, 48, None, None, 1, 1, None, None, None, None, None) == -1
+    assert b"null pointer" in lib.udp_last_error()
+    assert lib.udp_flip_fuse(None, None, None, None, 1, 1, 1, 1, None, None) == -1
+    assert lib.udp_mse_loss(None, None, None, 1, 1, 1, 0, None, None, None) == -1
+    buf = (C.c_float * 4)()
+    assert lib.udp_gaussian_taps_host(4, buf) == -1          # even kernel size
+    assert lib.udp_gaussian_taps_host(17, buf) == -1
+    h = C.c_void_p()
+    assert lib.udp_hrnet_create(None, 0, None, 0, None, 0, 0, 256, 192, 17, C.byref(h)) == -1
+    assert lib.udp_hrnet_workspace_bytes(None, 4, 0) == 0
+    assert lib.udp_hrnet_destroy(None) == 0
+
+
+def test_taps_match_documented_opencv_rule():
+    buf = (C.c_float * 7)()
+    assert _lib.lib().udp_gaussian_taps_host(7, buf) == 0
+    np.testing.assert_array_equal(np.frombuffer(buf, np.float32),
+                                  np.array([0.03125, 0.109375, 0.21875, 0.28125, 0.21875, 0.109375, 0.03125], np.float32))
+    buf = (C.c_float * 15)()
+    assert _lib.lib().udp_gaussian_taps_host(15, buf) == 0
+    t = np.frombuffer(buf, np.float32)
+    x = np.arange(15) - 7.0
+    ref = np.exp(-x * x / (2 * 2.6 ** 2))
+    np.testing.assert_allclose(t, ref / ref.sum(), rtol=1e-6)
+    assert abs(float(t.sum()) - 1.0) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_program_census_matches_survey(dtype):
+    sd = synth.synth_state_dict(synth.W32_EXTRA, 17, "gaussian", seed=0)
+    prog = hrnet_plan.HRNetProgram(sd, synth.W32_EXTRA, 256, 192, dtype)
+    kinds = [d[1] for d in prog.describe()]
+    assert kinds.count(_lib.UDP_OP_STEM) == 1
+    assert kinds.count(_lib.UDP_OP_STEM) + kinds.count(_lib.UDP_OP_CONV) == 294     # 294 convs
+    assert prog.macs_per_image() == 7670857728                                        # 7.671 GMAC
+    ops = prog.ops_array()
+    assert ops[len(ops) - 1].out_buf == _lib.UDP_BUF_OUTPUT and ops[len(ops) - 1].cout == 17
+    # no op reads and writes the same buffer; every up-sampled addend is lower resolution
+    for o in ops:
+        ins = [o.in_buf, o.res_buf] + [o.up_buf[u] for u in range(o.n_up)]
+        assert o.out_buf not in [b for b in ins if b >= 0]
+        assert all(1 <= o.up_shift[u] <= 3 for u in range(o.n_up))
+    blob = prog.weight_blob()
+    assert blob.nbytes % 256 == 0 and blob.nbytes > (57e6 if dtype == "bf16" else 114e6)
+
+
+def test_program_rejects_bad_configs():
+    sd = synth.synth_state_dict(synth.W32_EXTRA, 17, "gaussian", seed=0)
+    with pytest.raises(ValueError, match="multiple of 32"):
+        hrnet_plan.HRNetProgram(sd, synth.W32_EXTRA, 250, 192, "f32")
+    bad = {k: dict(v) if isinstance(v, dict) else v for k, v in synth.W32_EXTRA.items()}
+    bad["STAGE3"]["NUM_CHANNELS"] = [32, 64]
+    with pytest.raises(ValueError, match="NUM_BRANCHES"):
+        synth.hrnet_param_shapes(bad)
+
+
+def test_yaml_config_defaults(tmp_path):
+    p = tmp_path / "c.yaml"
+    p.write_text("MODEL:\n  TARGET_TYPE: offset\n  IMAGE_SIZE: [192, 256]\n  EXTRA:\n    FINAL_CONV_KERNEL: 1\nTEST:\n  POST_PROCESS: true\n")
+    cfg = load_config(str(p))
+    assert cfg.MODEL.TARGET_TYPE == "offset" and cfg.LOSS.KPD == 4.0 and cfg.TEST.POST_PROCESS is True
+    assert cfg["MODEL"]["EXTRA"]["FINAL_CONV_KERNEL"] == 1 and cfg.MODEL.NUM_JOINTS == 17

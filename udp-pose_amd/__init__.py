@@ -8,3 +8,23 @@ Host side (Python) mirrors the reference's call contracts -- ``get_final_preds``
 CPU fallback: importing a compute entry point without the built library raises.
 """
 __version__ = "0.1.0"
+
+from . import _lib  # noqa: E402
+from .config import load_config  # noqa: E402,F401
+
+
+def __getattr__(name):
+    """Lazy exports so that ``import udp_pose_amd`` works without torch being imported yet."""
+    if name in ("get_final_preds", "decode_device", "gaussian_taps"):
+        from . import inference
+        return getattr(inference, name)
+    if name in ("MODELS", "get_pose_net", "PoseHighResolutionNetHip"):
+        from . import model
+        return getattr(model, name)
+    if name in ("UdpPsaPoseHip", "UdpPsaPoseTorch", "box_to_center_scale", "warp_affine_device"):
+        from . import pose_engine
+        return getattr(pose_engine, name)
+    if name in ("flip_back", "flip_back_offset", "flip_fuse"):
+        from . import transforms
+        return getattr(transforms, name)
+    raise AttributeError(name)

@@ -1,0 +1,101 @@
+"""ctypes binding of libudp_pose_hip.so (include/udp_pose_hip.h).
+
+The library is built in-tree (``__graft_entry__.build()`` or
+``make -C udp-pose_amd/csrc``).  There is no CPU fallback: if the library is
+missing, ``lib()`` raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libudp_pose_hip.so")
+
+UDP_OK = 0
+UDP_F32, UDP_BF16 = 0, 1
+UDP_OP_STEM, UDP_OP_CONV, UDP_OP_FUSE = 0, 1, 2
+UDP_BUF_NONE, UDP_BUF_OUTPUT = -1, -2
+ABI_VERSION = 1
+
+
+class ConvOp(C.Structure):
+    """struct udp_conv_op (include/udp_pose_hip.h)."""
+    _fields_ = [
+        ("kind", C.c_int32), ("ks", C.c_int32), ("stride", C.c_int32), ("relu", C.c_int32),
+        ("cin", C.c_int32), ("cout", C.c_int32), ("cout_pad", C.c_int32),
+        ("hin", C.c_int32), ("win", C.c_int32), ("hout", C.c_int32), ("wout", C.c_int32),
+        ("in_buf", C.c_int32), ("out_buf", C.c_int32), ("res_buf", C.c_int32),
+        ("n_up", C.c_int32), ("up_buf", C.c_int32 * 3), ("up_shift", C.c_int32 * 3),
+        ("w_off", C.c_int64), ("b_off", C.c_int64),
+    ]
+
+
+class UdpPoseError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("udp_pose_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_P = C.c_void_p
+_SIGS = {
+    "udp_abi_version": (C.c_int, []),
+    "udp_last_error": (C.c_char_p, []),
+    "udp_hrnet_create": (C.c_int, [C.POINTER(ConvOp), C.c_int, C.POINTER(C.c_int64), C.c_int, _P,
+                                   C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "udp_hrnet_workspace_bytes": (C.c_size_t, [_P, C.c_int, C.c_int]),
+    "udp_hrnet_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_size_t, _P, C.c_int, _P]),
+    "udp_hrnet_destroy": (C.c_int, [_P]),
+    "udp_hrnet_num_launches": (C.c_int, [_P]),
+    "udp_hrnet_flops_per_image": (C.c_double, [_P]),
+    "udp_conv2d_fused": (C.c_int, [C.POINTER(ConvOp), C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "udp_flip_fuse": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "udp_decode_gaussian": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int,
+                                      _P, _P, _P, _P, _P]),
+    "udp_decode_offset": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_float,
+                                    _P, _P, _P, _P, _P]),
+    "udp_gaussian_taps_host": (C.c_int, [C.c_int, C.POINTER(C.c_float)]),
+    "udp_warp_affine": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int,
+                                  C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P]),
+    "udp_target_gaussian": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_float, _P, _P, _P]),
+    "udp_target_offset": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_float, _P, _P, _P]),
+    "udp_mse_loss": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+}
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+
+
+def lib():
+    """The loaded library.  Raises if it has not been built -- never falls back."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            f = getattr(l, name)
+            f.restype = res
+            f.argtypes = args
+        if l.udp_abi_version() != ABI_VERSION:
+            raise RuntimeError("libudp_pose_hip.so ABI %d != binding %d" % (l.udp_abi_version(), ABI_VERSION))
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != UDP_OK:
+        raise UdpPoseError(rc, lib().udp_last_error().decode("utf-8", "replace"))
+
+
+def ptr(t):
+    """Device/host pointer of a torch tensor (or None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(stream=None):
+    import torch
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return C.c_void_p(s.cuda_stream)

@@ -1,0 +1,55 @@
+// Shared host-side helpers of libudp_pose_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/udp_pose_hip.h"
+
+namespace udp {
+
+inline char* err_buf() {
+  static thread_local char buf[512] = {0};
+  return buf;
+}
+
+inline int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(err_buf(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define UDP_HIP_CHECK(expr)                                                                  \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return udp::fail(UDP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),   \
+                       __FILE__, __LINE__);                                                  \
+  } while (0)
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// Parameters of one fused conv launch (device-visible, passed by value).
+struct ConvParams {
+  const void* in;
+  void* out;
+  const void* wgt;
+  const float* bias;
+  const void* res;
+  const void* up[3];
+  int up_shift[3];
+  int nup;
+  int N, Hin, Win, Cin, Hout, Wout, Cout, CoutPad;
+  int G, R, TW;          // tile = G images x R rows x TW cols of output
+  int IH, IW;            // input halo tile per image
+  int tiles_x, tiles_y;  // tiles per image group
+  int relu;
+  int out_nchw_f32;      // epilogue writes NCHW fp32 (network output) instead of NHWC T
+  int flip_from;         // stem only: images >= flip_from read image (n - flip_from) mirrored in x
+};
+
+}  // namespace udp

@@ -1,0 +1,297 @@
+// HRNet forward executor: runs the host-built program of fused conv launches
+// (include/udp_pose_hip.h, udp_conv_op) on one HIP stream, optionally replaying
+// it as a hipGraph.  Replaces PoseHighResolutionNet.forward,
+// deep_hrnet/lib/models/pose_hrnet.py:436-471.
+#include <vector>
+
+#include "common.h"
+
+namespace udp {
+size_t conv_choose_tile(ConvParams& p, int ks, int stride, int* nb_out);
+int launch_conv(const ConvParams& p, int dtype, int ks, int stride, int nb, size_t lds, hipStream_t s);
+int launch_stem(const ConvParams& p, int dtype, hipStream_t s);
+int launch_fuse(const ConvParams& p, int dtype, hipStream_t s);
+}  // namespace udp
+
+using namespace udp;
+
+struct GraphEntry {
+  int n, flip;
+  const void* in;
+  void* ws;
+  void* out;
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+};
+
+struct udp_hrnet {
+  std::vector<udp_conv_op> ops;
+  std::vector<int64_t> buf_elems;  // per image, rounded up to 64 elements
+  std::vector<int64_t> buf_off;    // prefix sums (elements per image)
+  int64_t total_elems = 0;
+  const char* weights = nullptr;
+  size_t weights_bytes = 0;
+  int dtype = UDP_F32;
+  int in_h = 0, in_w = 0, out_channels = 0;
+  double flops = 0.0;
+  std::vector<GraphEntry> graphs;
+};
+
+static size_t esize(int dtype) { return dtype == UDP_F32 ? 4 : 2; }
+
+static int validate_op(const udp_hrnet* h, const udp_conv_op& o, int idx) {
+  const int nb = (int)h->buf_elems.size();
+  auto buf_ok = [&](int b, int64_t need) { return b >= 0 && b < nb && h->buf_elems[b] >= need; };
+  const int64_t out_need = (int64_t)o.hout * o.wout * o.cout;
+  if (o.kind < UDP_OP_STEM || o.kind > UDP_OP_FUSE) return fail(UDP_ERR_ARG, "op %d: bad kind %d", idx, o.kind);
+  if (o.cout <= 0 || o.hout <= 0 || o.wout <= 0 || o.cout_pad < o.cout || o.cout_pad % 32)
+    return fail(UDP_ERR_ARG, "op %d: bad output shape / cout_pad", idx);
+  if (o.out_buf == UDP_BUF_OUTPUT) {
+    if (o.kind != UDP_OP_CONV || o.cout != h->out_channels || o.hout * 4 != h->in_h || o.wout * 4 != h->in_w)
+      return fail(UDP_ERR_ARG, "op %d: output op must be a conv producing [C=%d,%d,%d]", idx, h->out_channels,
+                  h->in_h / 4, h->in_w / 4);
+    if (o.res_buf != UDP_BUF_NONE || o.n_up != 0) return fail(UDP_ERR_ARG, "op %d: output op takes no addends", idx);
+  } else if (!buf_ok(o.out_buf, out_need)) {
+    return fail(UDP_ERR_ARG, "op %d: out_buf %d missing or too small", idx, o.out_buf);
+  }
+  if (o.kind == UDP_OP_STEM) {
+    if (o.ks != 3 || o.stride != 2 || o.cin != 3 || o.hin != h->in_h || o.win != h->in_w)
+      return fail(UDP_ERR_ARG, "op %d: stem must be 3x3 s2 on the %dx%d input", idx, h->in_h, h->in_w);
+  } else {
+    if (!buf_ok(o.in_buf, (int64_t)o.hin * o.win * o.cin)) return fail(UDP_ERR_ARG, "op %d: in_buf %d missing or too small", idx, o.in_buf);
+    if (o.in_buf == o.out_buf) return fail(UDP_ERR_ARG, "op %d: in-place conv is not supported", idx);
+  }
+  if (o.kind != UDP_OP_FUSE) {
+    if ((o.ks != 1 && o.ks != 3) || (o.stride != 1 && o.stride != 2)) return fail(UDP_ERR_ARG, "op %d: ks/stride", idx);
+    const int pad = o.ks / 2;
+    if (o.hout != (o.hin + 2 * pad - o.ks) / o.stride + 1 || o.wout != (o.win + 2 * pad - o.ks) / o.stride + 1)
+      return fail(UDP_ERR_ARG, "op %d: output size does not match input/stride", idx);
+    const size_t wbytes = o.kind == UDP_OP_STEM ? (size_t)27 * o.cout * 4
+                                                : (size_t)o.ks * o.ks * o.cout_pad * o.cin * esize(h->dtype);
+    if (o.w_off < 0 || (size_t)o.w_off + wbytes > h->weights_bytes || (o.w_off & 15))
+      return fail(UDP_ERR_ARG, "op %d: weight range outside the blob or misaligned", idx);
+    if (o.b_off < 0 || (size_t)o.b_off + (size_t)o.cout_pad * 4 > h->weights_bytes || (o.b_off & 15))
+      return fail(UDP_ERR_ARG, "op %d: bias range outside the blob or misaligned", idx);
+  } else if (o.hin != o.hout || o.win != o.wout || o.cin != o.cout) {
+    return fail(UDP_ERR_ARG, "op %d: fuse op must keep the shape", idx);
+  }
+  if (o.res_buf != UDP_BUF_NONE && !buf_ok(o.res_buf, out_need)) return fail(UDP_ERR_ARG, "op %d: res_buf", idx);
+  if (o.n_up < 0 || o.n_up > 3) return fail(UDP_ERR_ARG, "op %d: n_up", idx);
+  for (int u = 0; u < o.n_up; ++u) {
+    const int s = o.up_shift[u];
+    if (s < 1 || s > 5 || (o.hout & ((1 << s) - 1)) || (o.wout & ((1 << s) - 1)))
+      return fail(UDP_ERR_ARG, "op %d: up_shift %d does not divide %dx%d", idx, s, o.hout, o.wout);
+    if (!buf_ok(o.up_buf[u], (int64_t)(o.hout >> s) * (o.wout >> s) * o.cout)) return fail(UDP_ERR_ARG, "op %d: up_buf %d", idx, u);
+  }
+  return UDP_OK;
+}
+
+extern "C" int udp_abi_version(void) { return UDP_POSE_ABI_VERSION; }
+extern "C" const char* udp_last_error(void) { return err_buf(); }
+
+extern "C" int udp_hrnet_create(const udp_conv_op* ops, int n_ops, const int64_t* buf_elems, int n_bufs,
+                                const void* weights_dev, size_t weights_bytes, int dtype, int in_h, int in_w,
+                                int out_channels, udp_hrnet** out) {
+  if (!ops || n_ops <= 0 || !buf_elems || n_bufs <= 0 || !weights_dev || !out)
+    return fail(UDP_ERR_ARG, "udp_hrnet_create: null/empty argument");
+  if (dtype != UDP_F32 && dtype != UDP_BF16) return fail(UDP_ERR_ARG, "udp_hrnet_create: dtype %d", dtype);
+  if (in_h <= 0 || in_w <= 0 || (in_h % 32) || (in_w % 32))
+    return fail(UDP_ERR_UNSUPPORTED, "udp_hrnet_create: input %dx%d must be a multiple of 32", in_h, in_w);
+  if (reinterpret_cast<uintptr_t>(weights_dev) & 15) return fail(UDP_ERR_ARG, "udp_hrnet_create: weights not 16-byte aligned");
+  udp_hrnet* h = new udp_hrnet();
+  h->dtype = dtype;
+  h->in_h = in_h;
+  h->in_w = in_w;
+  h->out_channels = out_channels;
+  h->weights = reinterpret_cast<const char*>(weights_dev);
+  h->weights_bytes = weights_bytes;
+  h->buf_off.resize(n_bufs);
+  for (int b = 0; b < n_bufs; ++b) {
+    if (buf_elems[b] <= 0) {
+      delete h;
+      return fail(UDP_ERR_ARG, "udp_hrnet_create: buffer %d has %lld elements", b, (long long)buf_elems[b]);
+    }
+    const int64_t e = (buf_elems[b] + 63) / 64 * 64;
+    h->buf_elems.push_back(e);
+    h->buf_off[b] = h->total_elems;
+    h->total_elems += e;
+  }
+  bool has_out = false;
+  for (int i = 0; i < n_ops; ++i) {
+    const int rc = validate_op(h, ops[i], i);
+    if (rc) {
+      delete h;
+      return rc;
+    }
+    has_out |= ops[i].out_buf == UDP_BUF_OUTPUT;
+    if (ops[i].kind != UDP_OP_FUSE)
+      h->flops += 2.0 * ops[i].ks * ops[i].ks * ops[i].cin * ops[i].cout * ops[i].hout * ops[i].wout;
+    h->ops.push_back(ops[i]);
+  }
+  if (!has_out || h->ops[0].kind != UDP_OP_STEM) {
+    delete h;
+    return fail(UDP_ERR_ARG, "udp_hrnet_create: program needs a stem op first and an output op");
+  }
+  *out = h;
+  return UDP_OK;
+}
+
+extern "C" size_t udp_hrnet_workspace_bytes(const udp_hrnet* h, int n, int flip_test) {
+  if (!h || n <= 0) return 0;
+  return (size_t)h->total_elems * (size_t)(n * (flip_test ? 2 : 1)) * esize(h->dtype);
+}
+
+extern "C" int udp_hrnet_num_launches(const udp_hrnet* h) { return h ? (int)h->ops.size() : 0; }
+extern "C" double udp_hrnet_flops_per_image(const udp_hrnet* h) { return h ? h->flops : 0.0; }
+
+static int enqueue_all(udp_hrnet* h, const float* in, int n, int flip, char* ws, float* out, hipStream_t s) {
+  const int B = n * (flip ? 2 : 1);
+  const size_t es = esize(h->dtype);
+  auto buf = [&](int b) -> char* { return ws + (size_t)h->buf_off[b] * B * es; };
+  for (size_t i = 0; i < h->ops.size(); ++i) {
+    const udp_conv_op& o = h->ops[i];
+    ConvParams p;
+    memset(&p, 0, sizeof(p));
+    p.N = B;
+    p.Hin = o.hin;
+    p.Win = o.win;
+    p.Cin = o.cin;
+    p.Hout = o.hout;
+    p.Wout = o.wout;
+    p.Cout = o.cout;
+    p.CoutPad = o.cout_pad;
+    p.relu = o.relu;
+    p.flip_from = flip ? n : B;
+    p.in = o.kind == UDP_OP_STEM ? reinterpret_cast<const void*>(in) : buf(o.in_buf);
+    p.out_nchw_f32 = o.out_buf == UDP_BUF_OUTPUT;
+    p.out = p.out_nchw_f32 ? reinterpret_cast<void*>(out) : buf(o.out_buf);
+    p.res = o.res_buf == UDP_BUF_NONE ? nullptr : buf(o.res_buf);
+    p.nup = o.n_up;
+    for (int u = 0; u < o.n_up; ++u) {
+      p.up[u] = buf(o.up_buf[u]);
+      p.up_shift[u] = o.up_shift[u];
+    }
+    if (o.kind != UDP_OP_FUSE) {
+      p.wgt = h->weights + o.w_off;
+      p.bias = reinterpret_cast<const float*>(h->weights + o.b_off);
+    }
+    int rc;
+    if (o.kind == UDP_OP_STEM) {
+      rc = launch_stem(p, h->dtype, s);
+    } else if (o.kind == UDP_OP_FUSE) {
+      rc = launch_fuse(p, h->dtype, s);
+    } else {
+      int nb = 2;
+      const size_t lds = conv_choose_tile(p, o.ks, o.stride, &nb);
+      rc = launch_conv(p, h->dtype, o.ks, o.stride, nb, lds, s);
+    }
+    if (rc) return rc;
+  }
+  return UDP_OK;
+}
+
+extern "C" int udp_hrnet_forward(udp_hrnet* h, const float* in_nchw, int n, int flip_test, void* workspace,
+                                 size_t workspace_bytes, float* heatmaps_nchw, int use_graph, void* stream) {
+  if (!h || !in_nchw || !workspace || !heatmaps_nchw) return fail(UDP_ERR_ARG, "udp_hrnet_forward: null pointer");
+  if (n <= 0) return fail(UDP_ERR_ARG, "udp_hrnet_forward: n=%d (the reference engine also requires n >= 1)", n);
+  if (workspace_bytes < udp_hrnet_workspace_bytes(h, n, flip_test))
+    return fail(UDP_ERR_WORKSPACE, "udp_hrnet_forward: workspace %zu < %zu bytes", workspace_bytes,
+                udp_hrnet_workspace_bytes(h, n, flip_test));
+  if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(UDP_ERR_ARG, "udp_hrnet_forward: workspace not 256-byte aligned");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  char* ws = reinterpret_cast<char*>(workspace);
+  flip_test = flip_test ? 1 : 0;
+  if (!use_graph) return enqueue_all(h, in_nchw, n, flip_test, ws, heatmaps_nchw, s);
+
+  for (auto& g : h->graphs)
+    if (g.n == n && g.flip == flip_test && g.in == in_nchw && g.ws == workspace && g.out == heatmaps_nchw) {
+      UDP_HIP_CHECK(hipGraphLaunch(g.exec, s));
+      return UDP_OK;
+    }
+  // First call for this (shape, buffers): run eagerly (also sets per-kernel attributes), then
+  // capture the same launch sequence for the following calls.
+  int rc = enqueue_all(h, in_nchw, n, flip_test, ws, heatmaps_nchw, s);
+  if (rc) return rc;
+  GraphEntry e;
+  e.n = n;
+  e.flip = flip_test;
+  e.in = in_nchw;
+  e.ws = workspace;
+  e.out = heatmaps_nchw;
+  hipStream_t cs;
+  UDP_HIP_CHECK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+  UDP_HIP_CHECK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+  rc = enqueue_all(h, in_nchw, n, flip_test, ws, heatmaps_nchw, cs);
+  hipError_t ce = hipStreamEndCapture(cs, &e.graph);
+  (void)hipStreamDestroy(cs);
+  if (rc) return rc;
+  if (ce != hipSuccess) return fail(UDP_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
+  UDP_HIP_CHECK(hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0));
+  if (h->graphs.size() >= 8) {
+    (void)hipGraphExecDestroy(h->graphs[0].exec);
+    (void)hipGraphDestroy(h->graphs[0].graph);
+    h->graphs.erase(h->graphs.begin());
+  }
+  h->graphs.push_back(e);
+  return UDP_OK;
+}
+
+extern "C" int udp_hrnet_destroy(udp_hrnet* h) {
+  if (!h) return UDP_OK;
+  for (auto& g : h->graphs) {
+    (void)hipGraphExecDestroy(g.exec);
+    (void)hipGraphDestroy(g.graph);
+  }
+  delete h;
+  return UDP_OK;
+}
+
+extern "C" int udp_conv2d_fused(const udp_conv_op* o, int dtype, int n, const void* in, const void* weights,
+                                const float* bias, const void* res, const void* up0, const void* up1,
+                                const void* up2, void* out, void* stream) {
+  if (!o || !in || !out) return fail(UDP_ERR_ARG, "udp_conv2d_fused: null pointer");
+  if (dtype != UDP_F32 && dtype != UDP_BF16) return fail(UDP_ERR_ARG, "udp_conv2d_fused: dtype %d", dtype);
+  if (n <= 0) return fail(UDP_ERR_ARG, "udp_conv2d_fused: n=%d", n);
+  if (o->kind != UDP_OP_CONV && o->kind != UDP_OP_FUSE) return fail(UDP_ERR_ARG, "udp_conv2d_fused: kind %d", o->kind);
+  if (o->kind == UDP_OP_CONV && (!weights || !bias)) return fail(UDP_ERR_ARG, "udp_conv2d_fused: conv needs weights and bias");
+  if (o->cout <= 0 || o->cout_pad < o->cout || o->cout_pad % 32 || o->n_up < 0 || o->n_up > 3)
+    return fail(UDP_ERR_ARG, "udp_conv2d_fused: bad cout/cout_pad/n_up");
+  if (o->kind == UDP_OP_CONV) {
+    if ((o->ks != 1 && o->ks != 3) || (o->stride != 1 && o->stride != 2)) return fail(UDP_ERR_ARG, "udp_conv2d_fused: ks/stride");
+    const int pad = o->ks / 2;
+    if (o->hout != (o->hin + 2 * pad - o->ks) / o->stride + 1 || o->wout != (o->win + 2 * pad - o->ks) / o->stride + 1)
+      return fail(UDP_ERR_ARG, "udp_conv2d_fused: output size does not match input/stride");
+  }
+  const void* ups[3] = {up0, up1, up2};
+  ConvParams p;
+  memset(&p, 0, sizeof(p));
+  p.N = n;
+  p.Hin = o->hin;
+  p.Win = o->win;
+  p.Cin = o->cin;
+  p.Hout = o->hout;
+  p.Wout = o->wout;
+  p.Cout = o->cout;
+  p.CoutPad = o->cout_pad;
+  p.relu = o->relu;
+  p.flip_from = n;
+  p.in = in;
+  p.out = out;
+  p.out_nchw_f32 = o->out_buf == UDP_BUF_OUTPUT;
+  p.res = res;
+  p.wgt = weights;
+  p.bias = bias;
+  p.nup = o->n_up;
+  for (int u = 0; u < o->n_up; ++u) {
+    const int s = o->up_shift[u];
+    if (!ups[u] || s < 1 || s > 5 || (o->hout & ((1 << s) - 1)) || (o->wout & ((1 << s) - 1)))
+      return fail(UDP_ERR_ARG, "udp_conv2d_fused: up %d", u);
+    p.up[u] = ups[u];
+    p.up_shift[u] = s;
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (o->kind == UDP_OP_FUSE) return launch_fuse(p, dtype, s);
+  int nb = 2;
+  const size_t lds = conv_choose_tile(p, o->ks, o->stride, &nb);
+  return launch_conv(p, dtype, o->ks, o->stride, nb, lds, s);
+}

@@ -1,0 +1,275 @@
+"""Host-side compiler: reference YAML (MODEL.EXTRA) + state_dict -> fused op program.
+
+Walks the same graph as PoseHighResolutionNet.forward
+(deep_hrnet/lib/models/pose_hrnet.py:436-471; modules :260-273, fuse layers
+:189-255, transitions :344-383, Bottleneck :62-100, BasicBlock :29-59) and
+emits one ``udp_conv_op`` (include/udp_pose_hip.h) per fused launch:
+
+    out = act( conv(in) + bias [+ res] [+ sum_k nearest_up(up_k)] )
+
+* BatchNorm(eval) is folded into the conv: w' = w * gamma/sqrt(var+eps),
+  b' = beta - mean*gamma/sqrt(var+eps), computed in fp64, stored fp32 / bf16.
+* An exchange-unit output y_i = ReLU(sum_j f_ij(x_j)) (:267-272) becomes: the
+  1x1 convs of the j>i terms write low-resolution temporaries; the last 3x3
+  stride-2 conv of each j<i chain adds the running sum (identity term, the
+  upsampled temporaries, earlier chains) in its epilogue, the final one applies
+  the ReLU; output 0 has no conv term and is one element-wise launch (or, in the
+  last stage-4 module, the epilogue of its 1x1 C->4C conv, :213-221).
+* Activation buffers are assigned by a linear scan over tensor lifetimes.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+BN_EPS = 1e-5
+
+
+class _T:
+    """An activation tensor (NHWC, per image) in SSA form."""
+    __slots__ = ("id", "c", "h", "w")
+
+    def __init__(self, i, c, h, w):
+        self.id, self.c, self.h, self.w = i, c, h, w
+
+    @property
+    def elems(self):
+        return self.c * self.h * self.w
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class HRNetProgram:
+    """The compiled program: ops (ctypes array), buffer sizes, packed weights."""
+
+    def __init__(self, state_dict, extra, in_h, in_w, dtype="f32"):
+        if dtype not in ("f32", "bf16"):
+            raise ValueError("dtype must be 'f32' or 'bf16'")
+        if in_h % 32 or in_w % 32:
+            raise ValueError("input %dx%d must be a multiple of 32" % (in_h, in_w))
+        self.sd = {k[7:] if k.startswith("module.") else k: v for k, v in state_dict.items()}
+        self.extra = extra
+        self.dtype = dtype
+        self.in_h, self.in_w = in_h, in_w
+        self._tensors = []
+        self._ops = []          # dicts with _T references
+        self._blob = []         # list of (offset, np.ndarray uint8)
+        self._blob_size = 0
+        self._build()
+        self._assign_buffers()
+
+    # ------------------------------------------------------------------ weights
+    def _put(self, arr_bytes):
+        off = _round_up(self._blob_size, 256)
+        self._blob.append((off, arr_bytes))
+        self._blob_size = off + len(arr_bytes)
+        return off
+
+    def _fold(self, conv, bn):
+        w = self.sd[conv + ".weight"].detach().to(torch.float64).cpu()
+        cout = w.shape[0]
+        bias = self.sd.get(conv + ".bias")
+        b = bias.detach().to(torch.float64).cpu() if bias is not None else torch.zeros(cout, dtype=torch.float64)
+        if bn is not None:
+            g = self.sd[bn + ".weight"].detach().to(torch.float64).cpu()
+            beta = self.sd[bn + ".bias"].detach().to(torch.float64).cpu()
+            mean = self.sd[bn + ".running_mean"].detach().to(torch.float64).cpu()
+            var = self.sd[bn + ".running_var"].detach().to(torch.float64).cpu()
+            s = g / torch.sqrt(var + BN_EPS)
+            w = w * s[:, None, None, None]
+            b = (b - mean) * s + beta
+        return w.to(torch.float32), b.to(torch.float32)
+
+    def _pack_conv(self, conv, bn):
+        w, b = self._fold(conv, bn)
+        cout, cin, kh, kw = w.shape
+        cout_pad = _round_up(cout, 32)
+        wp = torch.zeros(kh * kw, cout_pad, cin, dtype=torch.float32)
+        wp[:, :cout] = w.permute(2, 3, 0, 1).reshape(kh * kw, cout, cin)
+        if self.dtype == "bf16":
+            wbytes = wp.to(torch.bfloat16).contiguous().view(torch.uint8).numpy().tobytes()
+        else:
+            wbytes = wp.contiguous().numpy().tobytes()
+        bp = torch.zeros(cout_pad, dtype=torch.float32)
+        bp[:cout] = b
+        return self._put(wbytes), self._put(bp.numpy().tobytes()), cout, cin, kh, cout_pad
+
+    # ------------------------------------------------------------------ emission
+    def _new(self, c, h, w):
+        t = _T(len(self._tensors), c, h, w)
+        self._tensors.append(t)
+        return t
+
+    def _conv(self, x, conv, bn, stride=1, relu=True, res=None, ups=(), to_output=False):
+        w_off, b_off, cout, cin, ks, cout_pad = self._pack_conv(conv, bn)
+        if cin != x.c:
+            raise ValueError("%s: weight expects %d input channels, tensor has %d" % (conv, cin, x.c))
+        pad = ks // 2
+        ho = (x.h + 2 * pad - ks) // stride + 1
+        wo = (x.w + 2 * pad - ks) // stride + 1
+        out = None if to_output else self._new(cout, ho, wo)
+        self._ops.append(dict(kind=_lib.UDP_OP_CONV, ks=ks, stride=stride, relu=int(relu), cin=cin, cout=cout,
+                              cout_pad=cout_pad, hin=x.h, win=x.w, hout=ho, wout=wo, inp=x, out=out, res=res,
+                              ups=list(ups), w_off=w_off, b_off=b_off, name=conv))
+        return out
+
+    def _build(self):
+        sd = self.sd
+        H, W = self.in_h, self.in_w
+        # stem conv1 (VALU kernel on the NCHW fp32 input): weights fp32 [ky][kx][ci][cout]
+        w, b = self._fold("conv1", "bn1")
+        if tuple(w.shape) != (64, 3, 3, 3):
+            raise ValueError("conv1.weight must be [64,3,3,3]")
+        w_off = self._put(w.permute(2, 3, 1, 0).contiguous().numpy().tobytes())
+        b_off = self._put(b.numpy().tobytes())
+        x = self._new(64, H // 2, W // 2)
+        self._ops.append(dict(kind=_lib.UDP_OP_STEM, ks=3, stride=2, relu=1, cin=3, cout=64, cout_pad=64, hin=H,
+                              win=W, hout=H // 2, wout=W // 2, inp=None, out=x, res=None, ups=[], w_off=w_off,
+                              b_off=b_off, name="conv1"))
+        x = self._conv(x, "conv2", "bn2", stride=2)
+        for k in range(4):                                           # layer1 (:297, Bottleneck :80-100)
+            p = "layer1.%d" % k
+            a = self._conv(x, p + ".conv1", p + ".bn1")
+            bt = self._conv(a, p + ".conv2", p + ".bn2")
+            r = x
+            if (p + ".downsample.0.weight") in sd:
+                r = self._conv(x, p + ".downsample.0", p + ".downsample.1", relu=False)
+            x = self._conv(bt, p + ".conv3", p + ".bn3", res=r)
+        ys = [x]
+        for st in (2, 3, 4):
+            cfg = self.extra["STAGE%d" % st]
+            if cfg["BLOCK"] != "BASIC" or cfg.get("FUSE_METHOD", "SUM") != "SUM":
+                raise ValueError("stage %d: only BASIC blocks with SUM fusion are supported" % st)
+            nb = cfg["NUM_BRANCHES"]
+            if nb != len(cfg["NUM_BLOCKS"]) or nb != len(cfg["NUM_CHANNELS"]):
+                raise ValueError("NUM_BRANCHES(%d) <> NUM_BLOCKS/NUM_CHANNELS" % nb)   # pose_hrnet.py:121-139
+            xs = self._transition(ys, "transition%d" % (st - 1), nb)
+            for m in range(cfg["NUM_MODULES"]):
+                last = (st == 4 and m == cfg["NUM_MODULES"] - 1)
+                xs = self._module(xs, "stage%d.%d" % (st, m), cfg["NUM_BLOCKS"], last)
+            ys = xs
+        self._conv(ys[0], "final_layer", None, relu=False, to_output=True)
+        self.out_channels = self._ops[-1]["cout"]
+
+    def _transition(self, ys, name, n_cur):
+        xs = []
+        for i in range(n_cur):
+            q = "%s.%d" % (name, i)
+            if i < len(ys):
+                if (q + ".0.weight") in self.sd:
+                    xs.append(self._conv(ys[i], q + ".0", q + ".1"))
+                else:
+                    xs.append(ys[i])
+            else:
+                y = ys[-1]
+                for k in range(i + 1 - len(ys)):
+                    y = self._conv(y, "%s.%d.0" % (q, k), "%s.%d.1" % (q, k), stride=2)
+                xs.append(y)
+        return xs
+
+    def _module(self, xs, p, num_blocks, last):
+        nb = len(xs)
+        xs = list(xs)
+        for b in range(nb):
+            for k in range(num_blocks[b]):
+                q = "%s.branches.%d.%d" % (p, b, k)
+                t = self._conv(xs[b], q + ".conv1", q + ".bn1")
+                xs[b] = self._conv(t, q + ".conv2", q + ".bn2", res=xs[b])
+        n_out = 1 if last else nb
+        outs = []
+        for i in range(n_out):
+            ups = []
+            for j in range(i + 1, nb):
+                q = "%s.fuse_layers.%d.%d" % (p, i, j)
+                ups.append((self._conv(xs[j], q + ".0", q + ".1", relu=False), j - i))
+            if i == 0:
+                if last:
+                    outs.append(self._conv(xs[0], "%s.fuse_layers.0.0.0" % p, None, ups=ups))
+                else:
+                    out = self._new(xs[0].c, xs[0].h, xs[0].w)
+                    self._ops.append(dict(kind=_lib.UDP_OP_FUSE, ks=1, stride=1, relu=1, cin=xs[0].c, cout=xs[0].c,
+                                          cout_pad=_round_up(xs[0].c, 32), hin=xs[0].h, win=xs[0].w, hout=xs[0].h,
+                                          wout=xs[0].w, inp=xs[0], out=out, res=None, ups=ups, w_off=0, b_off=0,
+                                          name=p + ".fuse0"))
+                    outs.append(out)
+                continue
+            res, t = xs[i], None
+            for j in range(i):
+                t = xs[j]
+                for k in range(i - j):
+                    q = "%s.fuse_layers.%d.%d.%d" % (p, i, j, k)
+                    if k != i - j - 1:
+                        t = self._conv(t, q + ".0", q + ".1", stride=2)
+                    else:
+                        t = self._conv(t, q + ".0", q + ".1", stride=2, relu=(j == i - 1), res=res, ups=ups)
+                        res, ups = t, []
+            outs.append(t)
+        return outs
+
+    # ------------------------------------------------------------------ buffers
+    def _assign_buffers(self):
+        last_use = {}
+        for idx, op in enumerate(self._ops):
+            for t in [op["inp"], op["res"]] + [u for u, _ in op["ups"]]:
+                if t is not None:
+                    last_use[t.id] = idx
+        free = {}             # elems -> [buffer ids]
+        self.buf_elems = []
+        phys = {}
+        for idx, op in enumerate(self._ops):
+            out = op["out"]
+            if out is not None:
+                pool = free.get(out.elems)
+                if pool:
+                    phys[out.id] = pool.pop()
+                else:
+                    phys[out.id] = len(self.buf_elems)
+                    self.buf_elems.append(out.elems)
+            for t in [op["inp"], op["res"]] + [u for u, _ in op["ups"]]:
+                if t is not None and last_use.get(t.id) == idx and t.id in phys:
+                    free.setdefault(t.elems, []).append(phys[t.id])
+                    last_use[t.id] = -1
+        self._phys = phys
+
+    # ------------------------------------------------------------------ output
+    def ops_array(self):
+        arr = (_lib.ConvOp * len(self._ops))()
+        for i, op in enumerate(self._ops):
+            o = arr[i]
+            for f in ("kind", "ks", "stride", "relu", "cin", "cout", "cout_pad", "hin", "win", "hout", "wout",
+                      "w_off", "b_off"):
+                setattr(o, f, op[f])
+            o.in_buf = _lib.UDP_BUF_NONE if op["inp"] is None else self._phys[op["inp"].id]
+            o.out_buf = _lib.UDP_BUF_OUTPUT if op["out"] is None else self._phys[op["out"].id]
+            o.res_buf = _lib.UDP_BUF_NONE if op["res"] is None else self._phys[op["res"].id]
+            o.n_up = len(op["ups"])
+            for u, (t, s) in enumerate(op["ups"]):
+                o.up_buf[u] = self._phys[t.id]
+                o.up_shift[u] = s
+        return arr
+
+    def weight_blob(self):
+        blob = np.zeros(_round_up(self._blob_size, 256), dtype=np.uint8)
+        for off, b in self._blob:
+            blob[off:off + len(b)] = np.frombuffer(b, dtype=np.uint8)
+        return blob
+
+    def describe(self):
+        return [(op["name"], op["kind"], op["ks"], op["stride"], op["cin"], op["cout"], op["hout"], op["wout"])
+                for op in self._ops]
+
+    def macs_per_image(self):
+        return sum(op["ks"] ** 2 * op["cin"] * op["cout"] * op["hout"] * op["wout"]
+                   for op in self._ops if op["kind"] != _lib.UDP_OP_FUSE)
+
+    def activation_elems_per_image(self):
+        """Layer-wise algorithmic traffic: every op reads its inputs once and writes its output once."""
+        n = 0
+        for op in self._ops:
+            n += op["hin"] * op["win"] * op["cin"] + op["hout"] * op["wout"] * op["cout"]
+            if op["res"] is not None:
+                n += op["res"].elems
+            n += sum(t.elems for t, _ in op["ups"])
+        return n

@@ -1,0 +1,166 @@
+"""Model factory with the reference's contract: ``MODELS[cfg.MODEL.NAME](cfg, is_train)``.
+
+Mirrors deep_hrnet/lib/models/__init__.py:28-41 and pose_hrnet.py:508-514
+(``get_pose_net``): the returned object takes the reference's state_dict
+(``load_state_dict``, ``module.`` prefixes stripped as pose_engine.py:107-117
+does), ``.to(device)``, ``.eval()`` and is called on an NCHW fp32 batch,
+returning the heat-map tensor ``[N, J*(3 if offset else 1), H/4, W/4]`` fp32
+on the same device.  The forward runs entirely in libudp_pose_hip.so.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .hrnet_plan import HRNetProgram
+from .synth import hrnet_param_shapes
+
+
+def _get(cfg, *path):
+    cur = cfg
+    for p in path:
+        cur = cur[p] if isinstance(cur, dict) else getattr(cur, p)
+    return cur
+
+
+class PoseHighResolutionNetHip:
+    """HRNet (UDP variant) inference on MI355X through the C ABI."""
+
+    def __init__(self, cfg, dtype="f32"):
+        self.extra = _get(cfg, "MODEL", "EXTRA")
+        self.num_joints = int(_get(cfg, "MODEL", "NUM_JOINTS"))
+        self.target_type = _get(cfg, "MODEL", "TARGET_TYPE")
+        self.dtype = dtype
+        self.device = None
+        self.use_graph = True
+        self._sd = None
+        self._compiled = {}      # (h, w) -> (handle, blob tensor, program)
+        self._ws = None
+        self._io = {}
+        # same checks as HighResolutionModule._check_branches (pose_hrnet.py:121-139)
+        hrnet_param_shapes(self.extra, self.num_joints, self.target_type)
+
+    # ---- nn.Module-like surface used by the reference's callers
+    def load_state_dict(self, state_dict, strict=True):
+        sd = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+        want = hrnet_param_shapes(self.extra, self.num_joints, self.target_type)
+        missing = [k for k in want if k not in sd and not k.endswith("num_batches_tracked")]
+        unexpected = [k for k in sd if k not in want]
+        if strict and (missing or unexpected):
+            raise RuntimeError("state_dict mismatch: missing %s unexpected %s" % (missing[:5], unexpected[:5]))
+        if missing:
+            raise RuntimeError("state_dict lacks %d tensors the forward needs, e.g. %s" % (len(missing), missing[:3]))
+        for k, shape in want.items():
+            if k in sd and tuple(sd[k].shape) != tuple(shape):
+                raise RuntimeError("size mismatch for %s: %s vs %s" % (k, tuple(sd[k].shape), tuple(shape)))
+        self._sd = sd
+        self._release()
+        return self
+
+    def state_dict(self):
+        return dict(self._sd or {})
+
+    def to(self, device):
+        self.device = torch.device(device)
+        return self
+
+    def cuda(self):
+        return self.to("cuda")
+
+    def eval(self):
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("udp-pose_amd round 1 implements the inference path; training "
+                                      "(backward kernels) is not built yet")
+        return self
+
+    # ---- compile / run
+    def _release(self):
+        for h, _, _ in self._compiled.values():
+            _lib.lib().udp_hrnet_destroy(h)
+        self._compiled = {}
+        self._io = {}
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def _compile(self, h, w):
+        if self._sd is None:
+            raise RuntimeError("load_state_dict() first")
+        prog = HRNetProgram(self._sd, self.extra, h, w, self.dtype)
+        blob = torch.from_numpy(prog.weight_blob()).to(self.device)
+        ops = prog.ops_array()
+        bufs = (C.c_int64 * len(prog.buf_elems))(*prog.buf_elems)
+        handle = C.c_void_p()
+        _lib.check(_lib.lib().udp_hrnet_create(ops, len(ops), bufs, len(prog.buf_elems), _lib.ptr(blob),
+                                               blob.numel(), _lib.UDP_BF16 if self.dtype == "bf16" else _lib.UDP_F32,
+                                               h, w, prog.out_channels, C.byref(handle)))
+        self._compiled[(h, w)] = (handle, blob, prog)
+        return self._compiled[(h, w)]
+
+    def program(self, h, w):
+        if self.device is None:
+            self.to("cuda")
+        return (self._compiled.get((h, w)) or self._compile(h, w))[2]
+
+    def io_buffers(self, n, h, w, flip_test=False):
+        """Persistent (input [n,3,h,w], heat-maps [n*(1|2),C,h/4,w/4]) device buffers for this
+        shape.  Launch sequences are replayed as hipGraphs keyed on these addresses, so the
+        forward reads the network input from / writes heat-maps to the same memory every call."""
+        if self.device is None:
+            self.to("cuda")
+        key = (n, h, w, bool(flip_test))
+        io = self._io.get(key)
+        if io is None:
+            prog = self.program(h, w)
+            b = n * (2 if flip_test else 1)
+            io = (torch.empty(n, 3, h, w, dtype=torch.float32, device=self.device),
+                  torch.empty(b, prog.out_channels, h // 4, w // 4, dtype=torch.float32, device=self.device))
+            self._io[key] = io
+        return io
+
+    def raw_forward(self, x, flip_test=False):
+        """x: cuda fp32 [N,3,H,W] -> heat-maps [N*(2 if flip_test else 1), C, H/4, W/4]
+        (rows N.. are the raw outputs for the W-mirrored inputs).  The returned tensor is the
+        model's persistent output buffer: it is overwritten by the next call of the same shape
+        (the reference's callers ``.clone()`` it, pose_engine.py:125)."""
+        if self.device is None:
+            self.to(x.device)
+        if not x.is_cuda:
+            raise RuntimeError("udp-pose_amd has no CPU path: the input must live on the GPU")
+        if x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError("expected fp32 [N,3,H,W], got %s %s" % (x.dtype, tuple(x.shape)))
+        n, _, h, w = x.shape
+        if n < 1:
+            raise ValueError("empty batch (the reference's torch.stack of no crops raises too)")
+        handle, _, prog = self._compiled.get((h, w)) or self._compile(h, w)
+        xin, out = self.io_buffers(n, h, w, flip_test)
+        if x.data_ptr() != xin.data_ptr():
+            xin.copy_(x)
+        lib = _lib.lib()
+        need = lib.udp_hrnet_workspace_bytes(handle, n, int(flip_test))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        _lib.check(lib.udp_hrnet_forward(handle, _lib.ptr(xin), n, int(flip_test), _lib.ptr(self._ws),
+                                         self._ws.numel(), _lib.ptr(out), int(self.use_graph), _lib.stream_ptr()))
+        return out
+
+    def __call__(self, x):
+        return self.raw_forward(x, flip_test=False)
+
+    forward = __call__
+
+
+def get_pose_net(cfg, is_train, **kwargs):
+    """pose_hrnet.py:508-514.  ``is_train`` must be False in this round."""
+    if is_train:
+        raise NotImplementedError("training path (backward kernels) is not part of round 1")
+    return PoseHighResolutionNetHip(cfg, **kwargs)
+
+
+MODELS = {"pose_hrnet": get_pose_net}
