@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/s of the UDP-Pose hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic person crops that
+are already resident in HBM: HRNet-W32 256x192 forward on the batch AND on its
+W-mirrored copy (flip-test, one 2N-image launch sequence) -> flip fuse -> UDP decode
+(DARK / Taylor) -> keypoints [N,17,2] + maxvals on device.  Workload = BASELINE.json
+configs[1]: pose_hrnet_w32 256x192 bf16, batch 64 per GPU, flip-test on.
+
+    python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torch.distributed.run)
+
+Prints ONE JSON line (rank 0).  `value` is whole-job images/s; multi-GPU is weak scaling over
+independent replicas (every rank decodes its own batch; no data-path collective).  The line also
+carries `roofline` (dominant kernel class: algorithmic FLOPs / measured launch time vs the dense
+MFMA peak, from a hipEvent-instrumented pass of the same K steps) and `cpu_baseline` (the CPU
+oracle -- stock torch fp32 conv graph + NumPy decode, proven equal to the reference in
+tests/test_oracle_golden.py -- timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from udp_pose_amd import synth  # noqa: E402
+from udp_pose_amd.inference import decode_device  # noqa: E402
+from udp_pose_amd.model import MODELS  # noqa: E402
+from udp_pose_amd.transforms import COCO_FLIP_PAIRS, channel_map  # noqa: E402
+from udp_pose_amd import _lib  # noqa: E402
+
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # dense MFMA peaks, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def build_net(dtype, target_type="gaussian"):
+    calib_path = os.path.join(ROOT, "tests", "golden", "bn_calib_w32_%s.npz" % target_type)
+    calib = dict(np.load(calib_path)) if os.path.exists(calib_path) else None
+    sd = synth.synth_state_dict(synth.W32_EXTRA, 17, target_type, seed=0, bn_calib=calib)
+    cfg = {"MODEL": {"NAME": "pose_hrnet", "EXTRA": synth.W32_EXTRA, "NUM_JOINTS": 17, "TARGET_TYPE": target_type}}
+    net = MODELS["pose_hrnet"](cfg, is_train=False, dtype=dtype)
+    net.load_state_dict(sd, strict=True)
+    return sd, net
+
+
+class HotPath:
+    """forward(+mirrored) -> flip fuse -> decode, all on device, fixed buffers."""
+
+    def __init__(self, net, batch, device, seed):
+        self.net, self.n = net.to(device), batch
+        crops = synth.synth_crops(min(batch, 8), 256, 192, seed=seed)
+        reps = (batch + crops.shape[0] - 1) // crops.shape[0]
+        x = torch.from_numpy(np.tile(crops, (reps, 1, 1, 1))[:batch]).to(device)
+        x += 0.01 * torch.randn(x.shape, device=device, generator=torch.Generator(device).manual_seed(seed))
+        self.xin, _ = self.net.io_buffers(batch, 256, 192, True)
+        self.xin.copy_(x)
+        c, s = synth.synth_center_scale(batch, seed=seed)
+        self.center = torch.from_numpy(c.astype(np.float64)).to(device)
+        self.scale = torch.from_numpy(s.astype(np.float64)).to(device)
+        src, sign = channel_map(17, COCO_FLIP_PAIRS, False)
+        self.src = torch.from_numpy(src).to(device)
+        self.sign = torch.from_numpy(sign).to(device)
+        self.fused = torch.empty(batch, 17, 64, 48, device=device)
+
+    def step(self):
+        raw = self.net.raw_forward(self.xin, flip_test=True)
+        n = self.n
+        _lib.check(_lib.lib().udp_flip_fuse(_lib.ptr(raw), C_ptr(raw, n), _lib.ptr(self.src), _lib.ptr(self.sign),
+                                            n, 17, 64, 48, _lib.ptr(self.fused), _lib.stream_ptr()))
+        return decode_device(self.fused, self.center, self.scale, "gaussian", True, 4.0, True, want_idx=False)
+
+
+def C_ptr(t, row):
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr() + row * t.stride(0) * t.element_size())
+
+
+def roofline(net, hp, steps, dtype):
+    """hipEvent-instrumented pass: per-op times -> dominant kernel class."""
+    acc = None
+    for _ in range(steps):
+        ms, desc = net.profile(hp.xin, flip_test=True)
+        acc = ms if acc is None else acc + ms
+    ms = acc / steps
+    esz = 2 if dtype == "bf16" else 4
+    b = 2 * hp.n
+    classes = {}
+    for t, (name, kind, ks, stride, cin, cout, ho, wo) in zip(ms, desc):
+        key = "stem" if kind == 0 else ("fuse_sum" if kind == 2 else "conv%dx%d_s%d_nb%d" % (ks, ks, stride, 4 if cout > 32 else 2))
+        flops = 0.0 if kind == 2 else 2.0 * ks * ks * cin * cout * ho * wo * b
+        hin, win = ho * stride, wo * stride
+        byts = (hin * win * cin * (4 if kind == 0 else esz) + ho * wo * cout * esz) * b
+        c = classes.setdefault(key, [0.0, 0.0, 0.0, 0])
+        c[0] += float(t)
+        c[1] += flops
+        c[2] += byts
+        c[3] += 1
+    dom = max(classes, key=lambda k: classes[k][0])
+    t_ms, flops, byts, cnt = classes[dom]
+    achieved = flops / (t_ms * 1e-3) / 1e12
+    table = {k: {"ms": round(v[0], 4), "launches": v[3], "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 2) if v[0] > 0 else 0,
+                 "gbs": round(v[2] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else 0} for k, v in classes.items()}
+    return {"bound": "mfma", "kernel": "conv_mfma_kernel<%s> %s" % (dtype, dom), "achieved": round(achieved, 2),
+            "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS[dtype], 4),
+            "traffic": None, "launches_per_step": cnt, "avg_launch_us": round(t_ms / cnt * 1e3, 2),
+            "algorithmic_gflop_per_launch": round(flops / cnt / 1e9, 3),
+            "algorithmic_gbs_same_kernel": round(byts / (t_ms * 1e-3) / 1e9, 1),
+            "sum_kernel_ms_per_step": round(float(ms.sum()), 3), "classes": table}
+
+
+def cpu_baseline(sd, sample=8):
+    """The CPU oracle on this box's host cores: forward + mirrored forward + flip fuse + DARK decode."""
+    from oracle import decode as odec, flip as oflip, hrnet as ohrnet
+    cores = torch.get_num_threads()
+    x = torch.from_numpy(synth.synth_crops(sample, 256, 192, seed=1))
+    c, s = synth.synth_center_scale(sample, seed=1)
+
+    def run():
+        y = ohrnet.hrnet_forward(sd, synth.W32_EXTRA, torch.cat([x, torch.flip(x, dims=[3])])).numpy()
+        hm = oflip.flip_fuse(y[:sample], y[sample:], oflip.COCO_FLIP_PAIRS, False)
+        return odec.get_final_preds("gaussian", True, 4.0, hm.copy(), c, s), hm   # (post() mutates its input)
+
+    run()
+    t0 = time.time()
+    reps = 0
+    while reps < 2 or time.time() - t0 < 12.0:
+        (ref, hm) = run()
+        reps += 1
+    dt = (time.time() - t0) / reps
+    return {"value": round(sample / dt, 2), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "%d crops x %d reps, fp32 torch conv graph x2 (flip) + NumPy flip fuse + DARK decode" % (sample, reps)}, \
+        x, c, s, ref, hm
+
+
+def parity(net_dtype, sd, x, c, s, ref, ref_hm, device):
+    """Keypoint / heat-map agreement of the benchmarked mode with the CPU oracle on the baseline sample."""
+    out = {}
+    for dt in sorted({"f32", net_dtype}):
+        _, net = build_net(dt)
+        hp = HotPath(net, x.shape[0], device, seed=0)
+        hp.xin.copy_(x.to(device))
+        hp.center = torch.from_numpy(c.astype(np.float64)).to(device)
+        hp.scale = torch.from_numpy(s.astype(np.float64)).to(device)
+        preds, maxvals, _, _ = hp.step()
+        torch.cuda.synchronize()
+        err = np.abs(preds.cpu().numpy() - ref[0]).max(axis=2)
+        out[dt] = {"heatmap_max_abs_err": float(np.abs(hp.fused.cpu().numpy() - ref_hm).max()),
+                   "keypoint_err_px_median": float(np.median(err)), "keypoint_err_px_p90": float(np.percentile(err, 90))}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="crops per GPU per step")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    sd, net = build_net(args.dtype)
+    hp = HotPath(net, args.batch, device, seed=100 + rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        hp.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = hp.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(out[1]).all()
+    if dist is not None:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * args.batch * args.steps / dt
+
+    line = {"metric": "images/sec HRNet-W32 256x192 (infer+decode)", "value": round(value, 1), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": "pose_hrnet_w32 256x192 %s inference, batch=%d per GPU, flip-test on, DARK decode "
+                                   "(forward on 2N images + flip fuse + udp_decode_gaussian)" % (args.dtype, args.batch),
+                       "global_batch": world * args.batch, "parallelism": "replicas x%d (no data-path collective)" % world,
+                       "weights": "seeded synthetic, BN stats calibrated (tests/golden/bn_calib_w32_gaussian.npz)"}}
+    if rank == 0:
+        rl = roofline(net, hp, max(1, min(args.steps, 5)), args.dtype)
+        flops_per_img = 2 * 2 * net.program(256, 192).macs_per_image()
+        line["roofline"] = rl
+        line["whole_step"] = {"tflops": round(flops_per_img * args.batch / (ms_per_step * 1e-3) / 1e12, 2),
+                              "algorithmic_act_gbs": round(2 * net.program(256, 192).activation_elems_per_image() *
+                                                           (2 if args.dtype == "bf16" else 4) * args.batch /
+                                                           (ms_per_step * 1e-3) / 1e9, 1),
+                              "hbm_peak_gbs": PEAK_HBM_GBS}
+        if world == 1 and not args.no_cpu_baseline:
+            cb, x, c, s, ref, ref_hm = cpu_baseline(sd)
+            line["cpu_baseline"] = cb
+            line["parity_vs_cpu_oracle"] = parity(args.dtype, sd, x, c, s, ref, ref_hm, device)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

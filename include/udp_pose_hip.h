@@ -96,6 +96,11 @@ size_t udp_hrnet_workspace_bytes(const udp_hrnet* h, int n, int flip_test);
  * udp_flip_fuse).  use_graph != 0 replays a cached hipGraph of the launch sequence. */
 int udp_hrnet_forward(udp_hrnet* h, const float* in_nchw, int n, int flip_test, void* workspace,
                       size_t workspace_bytes, float* heatmaps_nchw, int use_graph, void* stream);
+/* Same launches as udp_hrnet_forward (eager, no graph) with a hipEvent pair around every op on
+ * `stream`; waits for completion and writes the elapsed milliseconds of op i to ms_per_op_host[i]
+ * (udp_hrnet_num_launches entries).  Measurement aid for bench.py's roofline section. */
+int udp_hrnet_profile(udp_hrnet* h, const float* in_nchw, int n, int flip_test, void* workspace,
+                      size_t workspace_bytes, float* heatmaps_nchw, float* ms_per_op_host, void* stream);
 int udp_hrnet_destroy(udp_hrnet* h);
 /* Number of kernel launches of one forward, and algorithmic FLOPs (2*MAC) per image. */
 int udp_hrnet_num_launches(const udp_hrnet* h);

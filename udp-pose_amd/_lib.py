@@ -43,6 +43,7 @@ _SIGS = {
                                    C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "udp_hrnet_workspace_bytes": (C.c_size_t, [_P, C.c_int, C.c_int]),
     "udp_hrnet_forward": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_size_t, _P, C.c_int, _P]),
+    "udp_hrnet_profile": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_size_t, _P, C.POINTER(C.c_float), _P]),
     "udp_hrnet_destroy": (C.c_int, [_P]),
     "udp_hrnet_num_launches": (C.c_int, [_P]),
     "udp_hrnet_flops_per_image": (C.c_double, [_P]),

@@ -198,8 +198,9 @@ __global__ __launch_bounds__(256) void decode_gaussian_kernel(
         yy = yy < 0 ? 0 : (yy >= h ? h - 1 : yy);
         xx = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
         const float rs = (blr[yy * w + xx] - mn) / range * maxori;
-        // np.clip / np.log propagate NaN (flat map: 0/0 in the rescale); fminf/fmaxf would not
-        s[dy + 1][dx + 1] = (rs == rs) ? (double)logf(fminf(fmaxf(rs, 0.001f), 50.0f)) : (double)NAN;
+        // np.clip / np.log propagate NaN (flat map: 0/0 in the rescale); fminf/fmaxf would not.
+        // fp32 log taken as the rounded fp64 log (correctly rounded, like NumPy's fp32 loop nearly always is)
+        s[dy + 1][dx + 1] = (rs == rs) ? (double)(float)log((double)fminf(fmaxf(rs, 0.001f), 50.0f)) : (double)NAN;
       }
     const double I = s[1][1], Ix1 = s[1][2], Ix1_ = s[1][0], Iy1 = s[2][1], Iy1_ = s[0][1];
     const double Ix1y1 = s[2][2], Ix1_y1_ = s[0][0];

@@ -144,7 +144,8 @@ extern "C" size_t udp_hrnet_workspace_bytes(const udp_hrnet* h, int n, int flip_
 extern "C" int udp_hrnet_num_launches(const udp_hrnet* h) { return h ? (int)h->ops.size() : 0; }
 extern "C" double udp_hrnet_flops_per_image(const udp_hrnet* h) { return h ? h->flops : 0.0; }
 
-static int enqueue_all(udp_hrnet* h, const float* in, int n, int flip, char* ws, float* out, hipStream_t s) {
+static int enqueue_all(udp_hrnet* h, const float* in, int n, int flip, char* ws, float* out, hipStream_t s,
+                       hipEvent_t* ev = nullptr) {
   const int B = n * (flip ? 2 : 1);
   const size_t es = esize(h->dtype);
   auto buf = [&](int b) -> char* { return ws + (size_t)h->buf_off[b] * B * es; };
@@ -176,6 +177,7 @@ static int enqueue_all(udp_hrnet* h, const float* in, int n, int flip, char* ws,
       p.bias = reinterpret_cast<const float*>(h->weights + o.b_off);
     }
     int rc;
+    if (ev) UDP_HIP_CHECK(hipEventRecord(ev[2 * i], s));
     if (o.kind == UDP_OP_STEM) {
       rc = launch_stem(p, h->dtype, s);
     } else if (o.kind == UDP_OP_FUSE) {
@@ -186,7 +188,28 @@ static int enqueue_all(udp_hrnet* h, const float* in, int n, int flip, char* ws,
       rc = launch_conv(p, h->dtype, o.ks, o.stride, nb, lds, s);
     }
     if (rc) return rc;
+    if (ev) UDP_HIP_CHECK(hipEventRecord(ev[2 * i + 1], s));
   }
+  return UDP_OK;
+}
+
+extern "C" int udp_hrnet_profile(udp_hrnet* h, const float* in_nchw, int n, int flip_test, void* workspace,
+                                 size_t workspace_bytes, float* heatmaps_nchw, float* ms_per_op, void* stream) {
+  if (!h || !in_nchw || !workspace || !heatmaps_nchw || !ms_per_op) return fail(UDP_ERR_ARG, "udp_hrnet_profile: null pointer");
+  if (n <= 0) return fail(UDP_ERR_ARG, "udp_hrnet_profile: n=%d", n);
+  if (workspace_bytes < udp_hrnet_workspace_bytes(h, n, flip_test)) return fail(UDP_ERR_WORKSPACE, "udp_hrnet_profile: workspace too small");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const size_t nops = h->ops.size();
+  std::vector<hipEvent_t> ev(2 * nops);
+  for (auto& e : ev) UDP_HIP_CHECK(hipEventCreate(&e));
+  int rc = enqueue_all(h, in_nchw, n, flip_test ? 1 : 0, reinterpret_cast<char*>(workspace), heatmaps_nchw, s, ev.data());
+  hipError_t se = hipStreamSynchronize(s);
+  if (!rc && se == hipSuccess)
+    for (size_t i = 0; i < nops; ++i)
+      if (hipEventElapsedTime(&ms_per_op[i], ev[2 * i], ev[2 * i + 1]) != hipSuccess) ms_per_op[i] = -1.f;
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  if (rc) return rc;
+  if (se != hipSuccess) return fail(UDP_ERR_HIP, "hipStreamSynchronize: %s", hipGetErrorString(se));
   return UDP_OK;
 }
 

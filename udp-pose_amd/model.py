@@ -150,6 +150,25 @@ class PoseHighResolutionNetHip:
                                          self._ws.numel(), _lib.ptr(out), int(self.use_graph), _lib.stream_ptr()))
         return out
 
+    def profile(self, x, flip_test=False):
+        """Per-op elapsed milliseconds (hipEvents around every launch, eager) and the op table:
+        returns (ms ndarray [n_ops], describe() list)."""
+        import numpy as np
+        n, _, h, w = x.shape
+        handle, _, prog = self._compiled.get((h, w)) or self._compile(h, w)
+        xin, out = self.io_buffers(n, h, w, flip_test)
+        if x.data_ptr() != xin.data_ptr():
+            xin.copy_(x)
+        lib = _lib.lib()
+        need = lib.udp_hrnet_workspace_bytes(handle, n, int(flip_test))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        nops = lib.udp_hrnet_num_launches(handle)
+        ms = (C.c_float * nops)()
+        _lib.check(lib.udp_hrnet_profile(handle, _lib.ptr(xin), n, int(flip_test), _lib.ptr(self._ws),
+                                         self._ws.numel(), _lib.ptr(out), ms, _lib.stream_ptr()))
+        return np.frombuffer(ms, dtype=np.float32).copy(), prog.describe()
+
     def __call__(self, x):
         return self.raw_forward(x, flip_test=False)
 
