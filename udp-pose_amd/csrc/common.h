@@ -47,6 +47,7 @@ struct ConvParams {
   int G, R, TW;          // tile = G images x R rows x TW cols of output
   int IH, IW;            // input halo tile per image
   int tiles_x, tiles_y;  // tiles per image group
+  unsigned mIW, mIH, mRT, mTW;  // ceil(2^32/d) (0 for d == 1): x/d == umulhi(x, m) for x < 65536
   int relu;
   int out_nchw_f32;      // epilogue writes NCHW fp32 (network output) instead of NHWC T
   int flip_from;         // stem only: images >= flip_from read image (n - flip_from) mirrored in x

@@ -10,11 +10,16 @@
 // conv_mfma_kernel: implicit GEMM on the matrix cores.  A workgroup (4 waves)
 // owns a tile of G images x R rows x TW columns of output pixels (M <= 256) and a
 // block of BN = 16*NB output channels.  Per chunk of CK input channels it stages
-// the input halo tile and the [tap][cout][cin-chunk] weights in LDS (80-byte rows:
-// 64 B payload + 16 B pad, conflict-free for the fragment reads below), then every
-// wave runs taps x k-steps of MFMA with  A = weights (rows = cout),
-// B = pixels (cols = pixel), so each lane ends up with 4 consecutive output
-// channels of one pixel -> one 8/16-byte NHWC store per accumulator tile.
+// the input halo tile and the [tap][cout][cin-chunk] weights in LDS with LDS-DMA
+// (global_load_lds_dwordx4: no VGPR staging, asynchronous) into 64-byte rows whose
+// four 16-byte parts are XOR-swizzled by the row index (conflict-free fragment
+// reads; the swizzle is applied on the per-lane SOURCE address because the DMA
+// destination is lane-linear).  Halo rows outside the image read a 64-byte zero
+// row.  Chunks are double-buffered: chunk c+1 streams in while chunk c feeds the
+// MFMAs (one barrier per chunk).  Every wave runs taps x k-steps of MFMA with
+// A = weights (rows = cout), B = pixels (cols = pixel); weight rows are permuted
+// at staging time so that a lane ends up with 4*NB CONSECUTIVE output channels of
+// one pixel -> 16-byte NHWC stores / residual loads in the epilogue.
 //   fp32 : v_mfma_f32_16x16x4_f32  (exact fp32 fma chain), ds_read_b64 feeds 2 MFMAs
 //   bf16 : v_mfma_f32_16x16x32_bf16 (fp32 accumulate),     ds_read_b128 feeds 1 MFMA
 #include <type_traits>
@@ -28,7 +33,21 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int ROWB = 80;  // LDS row pitch in bytes (pixel row / weight row)
+constexpr int ROWB = 64;   // LDS row: one pixel's (or one weight row's) 64-byte channel chunk
+constexpr int MAXG = 10;   // 16-row staging groups per wave for the input tile (<= 640 rows)
+
+__device__ uint4 g_zero_row[4];   // 64 zero bytes: DMA source for halo rows outside the image
+
+// 16-byte part p of LDS row r is stored at part position p ^ swz(r)
+__device__ __forceinline__ int swz(int row) { return (-(row >> 2)) & 3; }
+
+// x / d for x < 65536 with m = ceil(2^32 / d)
+__device__ __forceinline__ int fdiv(int x, unsigned m) { return m ? (int)__umulhi((unsigned)x, m) : x; }   // m == 0 <=> d == 1
+
+__device__ __forceinline__ void glds16(const char* src, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
 
 template <typename T>
 struct Tr;
@@ -64,21 +83,59 @@ __device__ __forceinline__ void store4<__bf16>(__bf16* p, f32x4 v) {
   *reinterpret_cast<bf16x4*>(p) = o;
 }
 
+// 4*NB consecutive channels <-> NB accumulator tiles of one lane
+template <typename T, int NB>
+__device__ __forceinline__ void add_vec(f32x4 (&v)[NB], const T* p) {
+  if constexpr (std::is_same<T, float>::value) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) v[nb] += *reinterpret_cast<const f32x4*>(p + 4 * nb);
+  } else {
+#pragma unroll
+    for (int h = 0; h < NB / 2; ++h) {
+      const bf16x8 x = *reinterpret_cast<const bf16x8*>(p + 8 * h);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v[2 * h][q] += (float)x[q];
+        v[2 * h + 1][q] += (float)x[4 + q];
+      }
+    }
+  }
+}
+template <typename T, int NB>
+__device__ __forceinline__ void store_vec(T* p, const f32x4 (&v)[NB]) {
+  if constexpr (std::is_same<T, float>::value) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) *reinterpret_cast<f32x4*>(p + 4 * nb) = v[nb];
+  } else {
+#pragma unroll
+    for (int h = 0; h < NB / 2; ++h) {
+      bf16x8 o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        o[q] = (__bf16)v[2 * h][q];
+        o[4 + q] = (__bf16)v[2 * h + 1][q];
+      }
+      *reinterpret_cast<bf16x8*>(p + 8 * h) = o;
+    }
+  }
+}
+
 template <typename T, int KS, int STRIDE, int NB>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
   constexpr int CK = Tr<T>::CK;
   constexpr int BN = NB * 16;
   constexpr int PAD = KS / 2;
   constexpr int TAPS = KS * KS;
+  constexpr int WGROUPS = TAPS * BN / 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15;
   const int kg = lane >> 4;
 
-  int t = blockIdx.x;
+  int t = blockIdx.x;   // wave-uniform: plain division (t may exceed the 16-bit range of fdiv)
   const int tx = t % p.tiles_x;
   t /= p.tiles_x;
   const int ty = t % p.tiles_y;
@@ -90,24 +147,75 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
 
   const int IH = p.IH, IW = p.IW;
   const int npix_in = p.G * IH * IW;
-  unsigned char* in_lds = smem;
-  unsigned char* w_lds = smem + (size_t)npix_in * ROWB;
+  const int in_groups = (npix_in + 15) >> 4;
+  const int in_bytes = in_groups * 16 * ROWB;
+  const int stage_bytes = in_bytes + TAPS * BN * ROWB;
+  const int nchunks = p.Cin / CK;
 
   const int RT = p.R * p.TW;
   const int M = p.G * RT;
   const int nmb = (M + 15) >> 4;
 
-  int a_off[4];
+  const char* in_base = reinterpret_cast<const char*>(p.in);
+  const char* w_base = reinterpret_cast<const char*>(p.wgt);
+  const char* zero = reinterpret_cast<const char*>(g_zero_row);
+
+  // ---- per-lane DMA sources of the input halo tile (same for every chunk)
+  const int srow = lane >> 2;  // row inside a 16-row group
+  const int spart = lane & 3;  // stored 16-byte part position
+  int src_off[MAXG];           // byte offset of (pixel, chunk 0, logical part), -1 = zero row (tensors < 2 GiB)
+#pragma unroll
+  for (int i = 0; i < MAXG; ++i) {
+    const int row = (wave + 4 * i) * 16 + srow;
+    int off = -1;
+    if (row < npix_in) {
+      const int tmp = fdiv(row, p.mIW);
+      const int ix = row - tmp * IW;
+      const int g = fdiv(tmp, p.mIH);
+      const int iy = tmp - g * IH;
+      const int n = n0 + g;
+      const int gy = y0 * STRIDE - PAD + iy;
+      const int gx = x0 * STRIDE - PAD + ix;
+      if (n < p.N && gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win)
+        off = (((n * p.Hin + gy) * p.Win + gx) * p.Cin) * (int)sizeof(T) + ((spart ^ swz(row)) << 4);
+    }
+    src_off[i] = off;
+  }
+
+  auto stage = [&](int c, unsigned char* sb) {
+    const int coff = c * CK * (int)sizeof(T);
+#pragma unroll
+    for (int i = 0; i < MAXG; ++i) {
+      const int gidx = wave + 4 * i;
+      if (gidx < in_groups) {
+        const int row = gidx * 16 + srow;
+        const char* src = src_off[i] >= 0 ? in_base + (unsigned)(src_off[i] + coff) : zero + ((spart ^ swz(row)) << 4);
+        glds16(src, sb + gidx * (16 * ROWB));
+      }
+    }
+    // weights: LDS row (tap, nb*16 + r) holds cout 4*NB*(r>>2) + 4*nb + (r&3) of this block
+    for (int gidx = wave; gidx < WGROUPS; gidx += 4) {
+      const int wr = gidx * 16 + srow;
+      const int tap = wr / BN;
+      const int rho = wr - tap * BN;
+      const int co = (4 * NB) * ((rho & 15) >> 2) + 4 * (rho >> 4) + (rho & 3);
+      const long e = ((long)(tap * p.CoutPad + cb * BN + co) * p.Cin) * (long)sizeof(T) + coff;
+      glds16(w_base + e + ((spart ^ swz(wr)) << 4), sb + in_bytes + gidx * (16 * ROWB));
+    }
+  };
+
+  int prow[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int m = (wave + 4 * i) * 16 + li;
     m = m < M ? m : M - 1;
-    const int g = m / RT;
+    const int g = fdiv(m, p.mRT);
     const int rem = m - g * RT;
-    const int r = rem / p.TW;
+    const int r = fdiv(rem, p.mTW);
     const int x = rem - r * p.TW;
-    a_off[i] = ((g * IH + r * STRIDE) * IW + x * STRIDE) * ROWB;
+    prow[i] = (g * IH + r * STRIDE) * IW + x * STRIDE;
   }
+  const int wswz = swz(li);  // weight rows: (tap*BN + nb*16) is a multiple of 16 -> swizzle depends on li only
 
   f32x4 acc[4][NB];
 #pragma unroll
@@ -115,57 +223,29 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) acc[i][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const char* in_base = reinterpret_cast<const char*>(p.in);
-  const char* w_base = reinterpret_cast<const char*>(p.wgt);
-
-  for (int c0 = 0; c0 < p.Cin; c0 += CK) {
-    if (c0) __syncthreads();
-    // ---- stage the input halo tile: 4 x 16-byte pieces per pixel
-    for (int piece = tid; piece < npix_in * 4; piece += 256) {
-      const int pix = piece >> 2, part = piece & 3;
-      const int ix = pix % IW;
-      const int tmp = pix / IW;
-      const int iy = tmp % IH;
-      const int g = tmp / IH;
-      const int n = n0 + g;
-      const int gy = y0 * STRIDE - PAD + iy;
-      const int gx = x0 * STRIDE - PAD + ix;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (n < p.N && gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win) {
-        const size_t e = ((size_t)(n * p.Hin + gy) * p.Win + gx) * p.Cin + c0;
-        v = *reinterpret_cast<const uint4*>(in_base + e * sizeof(T) + part * 16);
-      }
-      *reinterpret_cast<uint4*>(in_lds + pix * ROWB + part * 16) = v;
-    }
-    // ---- stage the weights of this cout block / cin chunk: rows = (tap, cout)
-    for (int piece = tid; piece < TAPS * BN * 4; piece += 256) {
-      const int row = piece >> 2, part = piece & 3;
-      const int tap = row / BN;
-      const int co = row - tap * BN;
-      const size_t e = ((size_t)(tap * p.CoutPad + cb * BN + co)) * p.Cin + c0;
-      const uint4 v = *reinterpret_cast<const uint4*>(w_base + e * sizeof(T) + part * 16);
-      *reinterpret_cast<uint4*>(w_lds + row * ROWB + part * 16) = v;
-    }
-    __syncthreads();
-
-    // ---- MFMA over taps x k-steps
+  stage(0, smem);
+  for (int c = 0; c < nchunks; ++c) {
+    __syncthreads();  // chunk c has landed (vmcnt(0)) and every wave is done with chunk c-1
+    if (c + 1 < nchunks) stage(c + 1, smem + ((c + 1) & 1) * stage_bytes);
+    const unsigned char* sb = smem + (c & 1) * stage_bytes;
+    const unsigned char* wb = sb + in_bytes + li * ROWB;
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
       const int ky = tap / KS, kx = tap % KS;
-      const int tap_off = (ky * IW + kx) * ROWB;
-      const unsigned char* wrow = w_lds + (tap * BN + li) * ROWB;
+      const int tap_rows = ky * IW + kx;
       if constexpr (std::is_same<T, float>::value) {
 #pragma unroll
-        for (int ks = 0; ks < CK / 8; ++ks) {
-          const int koff = ks * 32 + kg * 8;
+        for (int ks = 0; ks < 2; ++ks) {
+          const int part = 2 * ks + (kg >> 1), sub = (kg & 1) * 8;
           f32x2 wf[NB];
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb)
-            wf[nb] = *reinterpret_cast<const f32x2*>(wrow + nb * 16 * ROWB + koff);
+            wf[nb] = *reinterpret_cast<const f32x2*>(wb + (tap * BN + nb * 16) * ROWB + ((part ^ wswz) << 4) + sub);
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             if (wave + 4 * i < nmb) {
-              const f32x2 pf = *reinterpret_cast<const f32x2*>(in_lds + a_off[i] + tap_off + koff);
+              const int row = prow[i] + tap_rows;
+              const f32x2 pf = *reinterpret_cast<const f32x2*>(sb + row * ROWB + ((part ^ swz(row)) << 4) + sub);
 #pragma unroll
               for (int nb = 0; nb < NB; ++nb) {
                 acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nb][0], pf[0], acc[i][nb], 0, 0, 0);
@@ -175,15 +255,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
           }
         }
       } else {
-        const int koff = kg * 16;
         bf16x8 wf[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
-          wf[nb] = *reinterpret_cast<const bf16x8*>(wrow + nb * 16 * ROWB + koff);
+          wf[nb] = *reinterpret_cast<const bf16x8*>(wb + (tap * BN + nb * 16) * ROWB + ((kg ^ wswz) << 4));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           if (wave + 4 * i < nmb) {
-            const bf16x8 pf = *reinterpret_cast<const bf16x8*>(in_lds + a_off[i] + tap_off + koff);
+            const int row = prow[i] + tap_rows;
+            const bf16x8 pf = *reinterpret_cast<const bf16x8*>(sb + row * ROWB + ((kg ^ swz(row)) << 4));
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
               acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb], pf, acc[i][nb], 0, 0, 0);
@@ -193,52 +273,58 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     }
   }
 
-  // ---- epilogue: lane holds couts cbase+0..3 of pixel m
+  // ---- epilogue: lane holds couts cbase .. cbase + 4*NB - 1 of pixel m (acc[i][nb][q] = cbase + 4*nb + q)
+  const int cbase = cb * BN + 4 * NB * kg;
+  f32x4 bias[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) bias[nb] = *reinterpret_cast<const f32x4*>(p.bias + cbase + 4 * nb);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = (wave + 4 * i) * 16 + li;
     if (m >= M) continue;
-    const int g = m / RT;
+    const int g = fdiv(m, p.mRT);
     const int rem = m - g * RT;
-    const int r = rem / p.TW;
+    const int r = fdiv(rem, p.mTW);
     const int xo = x0 + rem - r * p.TW;
     const int n = n0 + g;
     const int y = y0 + r;
     if (n >= p.N || y >= p.Hout || xo >= p.Wout) continue;
     const size_t pix = ((size_t)(n * p.Hout + y) * p.Wout + xo);
+    f32x4 v[NB];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      const int c = cb * BN + nb * 16 + kg * 4;
-      f32x4 v = acc[i][nb];
-      const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + c);
-      v += b;
-      if (p.out_nchw_f32) {
-        float* o = reinterpret_cast<float*>(p.out);
+    for (int nb = 0; nb < NB; ++nb) v[nb] = acc[i][nb] + bias[nb];
+    if (p.out_nchw_f32) {
+      float* o = reinterpret_cast<float*>(p.out);
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (c + q < p.Cout) {
-            float f = v[q];
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = cbase + 4 * nb + q;
+          if (c < p.Cout) {
+            float f = v[nb][q];
             if (p.relu) f = f > 0.f ? f : 0.f;
-            o[((size_t)(n * p.Cout + c + q) * p.Hout + y) * p.Wout + xo] = f;
+            o[((size_t)(n * p.Cout + c) * p.Hout + y) * p.Wout + xo] = f;
           }
-        continue;
-      }
-      if (c >= p.Cout) continue;
-      if (p.res) v += load4<T>(reinterpret_cast<const T*>(p.res) + pix * p.Cout + c);
-#pragma unroll
-      for (int u = 0; u < 3; ++u) {
-        if (u < p.nup) {
-          const int s = p.up_shift[u];
-          const size_t up_pix = ((size_t)(n * (p.Hout >> s) + (y >> s)) * (p.Wout >> s) + (xo >> s));
-          v += load4<T>(reinterpret_cast<const T*>(p.up[u]) + up_pix * p.Cout + c);
         }
-      }
-      if (p.relu) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.f;
-      }
-      store4<T>(reinterpret_cast<T*>(p.out) + pix * p.Cout + c, v);
+      continue;
     }
+    if (cbase >= p.Cout) continue;   // NHWC: Cout is a multiple of 16 = 4*NB*k, whole vectors only
+    if (p.res) add_vec<T, NB>(v, reinterpret_cast<const T*>(p.res) + pix * p.Cout + cbase);
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      if (u < p.nup) {
+        const int s = p.up_shift[u];
+        const size_t up_pix = ((size_t)(n * (p.Hout >> s) + (y >> s)) * (p.Wout >> s) + (xo >> s));
+        add_vec<T, NB>(v, reinterpret_cast<const T*>(p.up[u]) + up_pix * p.Cout + cbase);
+      }
+    }
+    if (p.relu) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[nb][q] = v[nb][q] > 0.f ? v[nb][q] : 0.f;
+    }
+    store_vec<T, NB>(reinterpret_cast<T*>(p.out) + pix * p.Cout + cbase, v);
   }
 }
 
@@ -341,9 +427,11 @@ static int largest_divisor_leq(int n, int lim) {
   return 1;
 }
 
-// Picks the (G, R, TW) tile and NB for one conv; returns LDS bytes.
-size_t conv_choose_tile(ConvParams& p, int ks, int stride, int* nb_out) {
+// Picks the (G, R, TW) tile and NB for one conv; returns the dynamic LDS bytes.
+size_t conv_choose_tile(ConvParams& p, int ks, int stride, int dtype, int* nb_out) {
   const int kMaxM = 256;
+  const int ck = dtype == UDP_F32 ? 16 : 32;
+  const int nstage = p.Cin / ck > 1 ? 2 : 1;
   int TW = p.Wout;
   while (TW > 64) TW = (TW + 1) / 2;
   int maxR = kMaxM / TW;
@@ -357,14 +445,22 @@ size_t conv_choose_tile(ConvParams& p, int ks, int stride, int* nb_out) {
     if (G < 1) G = 1;
     if (G > p.N) G = p.N;
   }
-  int NB = p.CoutPad >= 64 ? 4 : 2;
-  auto lds = [&](int g, int r) {
-    const int ih = (r - 1) * stride + ks, iw = (TW - 1) * stride + ks;
-    return (size_t)(g * ih * iw + ks * ks * NB * 16) * ROWB;
+  int NB = (p.CoutPad % 64 == 0) ? 4 : 2;
+  auto npix = [&](int g, int r) { return g * ((r - 1) * stride + ks) * ((TW - 1) * stride + ks); };
+  auto lds = [&](int g, int r, int nb) {
+    return (size_t)(((npix(g, r) + 15) / 16) * 16 + ks * ks * nb * 16) * ROWB * nstage;
   };
-  const size_t kLimit = 72 * 1024;
-  while (lds(G, R) > kLimit && G > 1) --G;
-  while (lds(G, R) > kLimit && R > 1) R = (R + 1) / 2;
+  auto wgs = [&](int g, int r, int nb) {
+    return (long)ceil_div(p.N, g) * ceil_div(p.Hout, r) * ceil_div(p.Wout, TW) * (p.CoutPad / (nb * 16));
+  };
+  // small problems: trade tile size for workgroups (256 CUs, aim for >= 2 per CU)
+  const long kMinWgs = 512;
+  if (wgs(G, R, NB) < kMinWgs && NB == 4) NB = 2;
+  while (wgs(G, R, NB) < kMinWgs && G > 1) G = (G + 1) / 2;
+  const size_t kLimit = 76 * 1024;   // two workgroups per CU
+  while ((lds(G, R, NB) > kLimit || npix(G, R) > MAXG * 64) && G > 1) --G;
+  while ((lds(G, R, NB) > kLimit || npix(G, R) > MAXG * 64) && NB == 4) NB = 2;
+  while ((lds(G, R, NB) > kLimit || npix(G, R) > MAXG * 64) && R > 1) R = (R + 1) / 2;
   p.G = G;
   p.R = R;
   p.TW = TW;
@@ -372,8 +468,13 @@ size_t conv_choose_tile(ConvParams& p, int ks, int stride, int* nb_out) {
   p.IW = (TW - 1) * stride + ks;
   p.tiles_x = ceil_div(p.Wout, TW);
   p.tiles_y = ceil_div(p.Hout, R);
+  auto magic = [](int d) { return (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); };
+  p.mIW = magic(p.IW);
+  p.mIH = magic(p.IH);
+  p.mRT = magic(R * TW);
+  p.mTW = magic(TW);
   *nb_out = NB;
-  return lds(G, R);
+  return lds(G, R, NB);
 }
 
 template <typename T, int KS, int STRIDE, int NB>

@@ -7,7 +7,7 @@
 #include "common.h"
 
 namespace udp {
-size_t conv_choose_tile(ConvParams& p, int ks, int stride, int* nb_out);
+size_t conv_choose_tile(ConvParams& p, int ks, int stride, int dtype, int* nb_out);
 int launch_conv(const ConvParams& p, int dtype, int ks, int stride, int nb, size_t lds, hipStream_t s);
 int launch_stem(const ConvParams& p, int dtype, hipStream_t s);
 int launch_fuse(const ConvParams& p, int dtype, hipStream_t s);
@@ -184,7 +184,7 @@ static int enqueue_all(udp_hrnet* h, const float* in, int n, int flip, char* ws,
       rc = launch_fuse(p, h->dtype, s);
     } else {
       int nb = 2;
-      const size_t lds = conv_choose_tile(p, o.ks, o.stride, &nb);
+      const size_t lds = conv_choose_tile(p, o.ks, o.stride, h->dtype, &nb);
       rc = launch_conv(p, h->dtype, o.ks, o.stride, nb, lds, s);
     }
     if (rc) return rc;
@@ -315,6 +315,6 @@ extern "C" int udp_conv2d_fused(const udp_conv_op* o, int dtype, int n, const vo
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (o->kind == UDP_OP_FUSE) return launch_fuse(p, dtype, s);
   int nb = 2;
-  const size_t lds = conv_choose_tile(p, o->ks, o->stride, &nb);
+  const size_t lds = conv_choose_tile(p, o->ks, o->stride, dtype, &nb);
   return launch_conv(p, dtype, o->ks, o->stride, nb, lds, s);
 }
