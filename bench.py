@@ -162,6 +162,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="crops per GPU per step")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches on lane streams instead of hipGraph replay")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -180,6 +181,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=device)
 
     sd, net = build_net(args.dtype)
+    net.use_graph = not args.no_graph
     hp = HotPath(net, args.batch, device, seed=100 + rank)
 
     def barrier():

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UDP_POSE_ABI_VERSION 1
+#define UDP_POSE_ABI_VERSION 2
 
 enum udp_status {
   UDP_OK = 0,
@@ -63,6 +63,8 @@ enum udp_op_kind {
   UDP_OP_FUSE = 2  /* no conv: out = act(in + sum_k nearest_up(up_k))          */
 };
 
+#define UDP_MAX_LANES 4
+#define UDP_MAX_WAIT 8
 #define UDP_BUF_NONE (-1)
 #define UDP_BUF_OUTPUT (-2) /* out_buf: the NCHW fp32 heat-map output of the net */
 
@@ -80,6 +82,10 @@ typedef struct udp_conv_op {
   int64_t w_off;           /* byte offset in the weight blob: [ks*ks][cout_pad][cin] in dtype
                               (UDP_OP_STEM: fp32 [27][cout]) */
   int64_t b_off;           /* byte offset of the fp32 bias [cout_pad] */
+  int32_t lane;            /* 0..UDP_MAX_LANES-1: ops of different lanes may run concurrently
+                              (HRNet branches); lane 0 runs on the caller's stream */
+  int32_t n_wait;          /* cross-lane dependencies: this op starts after ops wait_op[0..n_wait) */
+  int32_t wait_op[UDP_MAX_WAIT];
 } udp_conv_op;
 
 typedef struct udp_hrnet udp_hrnet; /* opaque */

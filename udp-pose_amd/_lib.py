@@ -14,7 +14,8 @@ UDP_OK = 0
 UDP_F32, UDP_BF16 = 0, 1
 UDP_OP_STEM, UDP_OP_CONV, UDP_OP_FUSE = 0, 1, 2
 UDP_BUF_NONE, UDP_BUF_OUTPUT = -1, -2
-ABI_VERSION = 1
+ABI_VERSION = 2
+MAX_LANES, MAX_WAIT = 4, 8
 
 
 class ConvOp(C.Structure):
@@ -26,6 +27,7 @@ class ConvOp(C.Structure):
         ("in_buf", C.c_int32), ("out_buf", C.c_int32), ("res_buf", C.c_int32),
         ("n_up", C.c_int32), ("up_buf", C.c_int32 * 3), ("up_shift", C.c_int32 * 3),
         ("w_off", C.c_int64), ("b_off", C.c_int64),
+        ("lane", C.c_int32), ("n_wait", C.c_int32), ("wait_op", C.c_int32 * 8),
     ]
 
 

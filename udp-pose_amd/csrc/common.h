@@ -47,10 +47,21 @@ struct ConvParams {
   int G, R, TW;          // tile = G images x R rows x TW cols of output
   int IH, IW;            // input halo tile per image
   int tiles_x, tiles_y;  // tiles per image group
+  int ntiles;            // all tiles of the launch (persistent workgroups stride over them)
   unsigned mIW, mIH, mRT, mTW;  // ceil(2^32/d) (0 for d == 1): x/d == umulhi(x, m) for x < 65536
   int relu;
   int out_nchw_f32;      // epilogue writes NCHW fp32 (network output) instead of NHWC T
   int flip_from;         // stem only: images >= flip_from read image (n - flip_from) mirrored in x
 };
 
+}  // namespace udp
+
+namespace udp {
+// One kernel launch, described once and then either enqueued on a stream or added to a hipGraph.
+struct Launch {
+  const void* fn;
+  dim3 grid, block;
+  unsigned lds;
+  ConvParams p;
+};
 }  // namespace udp

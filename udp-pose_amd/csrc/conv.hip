@@ -225,7 +225,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
 
   stage(0, smem);
   for (int c = 0; c < nchunks; ++c) {
-    __syncthreads();  // chunk c has landed (vmcnt(0)) and every wave is done with chunk c-1
+    // chunk c has landed (explicit wait: the compiler is not obliged to track LDS-DMA) and every
+    // wave is done with chunk c-1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (c + 1 < nchunks) stage(c + 1, smem + ((c + 1) & 1) * stage_bytes);
     const unsigned char* sb = smem + (c & 1) * stage_bytes;
     const unsigned char* wb = sb + in_bytes + li * ROWB;
@@ -478,62 +481,76 @@ size_t conv_choose_tile(ConvParams& p, int ks, int stride, int dtype, int* nb_ou
 }
 
 template <typename T, int KS, int STRIDE, int NB>
-static int launch_one(const ConvParams& p, size_t lds, hipStream_t s) {
+static int describe_one(const ConvParams& p, size_t lds, Launch* out) {
   static bool attr_set = false;
-  auto kern = conv_mfma_kernel<T, KS, STRIDE, NB>;
+  const void* kern = reinterpret_cast<const void*>(&conv_mfma_kernel<T, KS, STRIDE, NB>);
   if (!attr_set) {
-    UDP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    UDP_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  const dim3 grid(ceil_div(p.N, p.G) * p.tiles_y * p.tiles_x, p.CoutPad / (NB * 16));
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
-  UDP_HIP_CHECK(hipGetLastError());
+  out->fn = kern;
+  out->grid = dim3(ceil_div(p.N, p.G) * p.tiles_y * p.tiles_x, p.CoutPad / (NB * 16));
+  out->block = dim3(256);
+  out->lds = (unsigned)lds;
+  out->p = p;
   return UDP_OK;
 }
 
 template <typename T>
-static int launch_conv_t(const ConvParams& p, int ks, int stride, int nb, size_t lds, hipStream_t s) {
+static int describe_conv_t(const ConvParams& p, int ks, int stride, int nb, size_t lds, Launch* out) {
 #define UDP_CASE(K, S, B) \
-  if (ks == K && stride == S && nb == B) return launch_one<T, K, S, B>(p, lds, s);
+  if (ks == K && stride == S && nb == B) return describe_one<T, K, S, B>(p, lds, out);
   UDP_CASE(3, 1, 2) UDP_CASE(3, 1, 4) UDP_CASE(3, 2, 2) UDP_CASE(3, 2, 4)
   UDP_CASE(1, 1, 2) UDP_CASE(1, 1, 4)
 #undef UDP_CASE
   return fail(UDP_ERR_UNSUPPORTED, "conv ks=%d stride=%d nb=%d has no kernel", ks, stride, nb);
 }
 
-int launch_conv(const ConvParams& p, int dtype, int ks, int stride, int nb, size_t lds, hipStream_t s) {
+// Fills `out` with the kernel, grid and arguments of one fused conv (tile choice included).
+int describe_conv(ConvParams p, int dtype, int ks, int stride, Launch* out) {
   if (p.Cin % 32 != 0) return fail(UDP_ERR_UNSUPPORTED, "conv Cin=%d is not a multiple of 32", p.Cin);
-  if (p.CoutPad % (nb * 16) != 0)
-    return fail(UDP_ERR_UNSUPPORTED, "conv CoutPad=%d is not a multiple of %d", p.CoutPad, nb * 16);
   if (!p.out_nchw_f32 && p.Cout % 16 != 0)
     return fail(UDP_ERR_UNSUPPORTED, "NHWC conv Cout=%d is not a multiple of 16", p.Cout);
-  if (dtype == UDP_F32) return launch_conv_t<float>(p, ks, stride, nb, lds, s);
-  return launch_conv_t<__bf16>(p, ks, stride, nb, lds, s);
+  const size_t esz = dtype == UDP_F32 ? 4 : 2;
+  if ((size_t)p.N * p.Hin * p.Win * p.Cin * esz >= 0x7FFF0000u)
+    return fail(UDP_ERR_UNSUPPORTED, "conv input exceeds the 2 GiB the 32-bit staging offsets cover; split the batch");
+  int nb = 2;
+  const size_t lds = conv_choose_tile(p, ks, stride, dtype, &nb);
+  if (p.CoutPad % (nb * 16) != 0)
+    return fail(UDP_ERR_UNSUPPORTED, "conv CoutPad=%d is not a multiple of %d", p.CoutPad, nb * 16);
+  if (dtype == UDP_F32) return describe_conv_t<float>(p, ks, stride, nb, lds, out);
+  return describe_conv_t<__bf16>(p, ks, stride, nb, lds, out);
 }
 
-int launch_stem(const ConvParams& p, int dtype, hipStream_t s) {
+int describe_stem(const ConvParams& p, int dtype, Launch* out) {
   if (p.Cout != 64) return fail(UDP_ERR_UNSUPPORTED, "stem conv expects 64 output channels, got %d", p.Cout);
   const long total = (long)p.N * p.Hout * p.Wout;
-  const dim3 grid((unsigned)((total + 63) / 64));
-  if (dtype == UDP_F32)
-    hipLaunchKernelGGL(stem_conv_kernel<float>, grid, dim3(256), 0, s, p);
-  else
-    hipLaunchKernelGGL(stem_conv_kernel<__bf16>, grid, dim3(256), 0, s, p);
-  UDP_HIP_CHECK(hipGetLastError());
+  out->fn = dtype == UDP_F32 ? reinterpret_cast<const void*>(&stem_conv_kernel<float>)
+                             : reinterpret_cast<const void*>(&stem_conv_kernel<__bf16>);
+  out->grid = dim3((unsigned)((total + 63) / 64));
+  out->block = dim3(256);
+  out->lds = 0;
+  out->p = p;
   return UDP_OK;
 }
 
-int launch_fuse(const ConvParams& p, int dtype, hipStream_t s) {
+int describe_fuse(const ConvParams& p, int dtype, Launch* out) {
   if (p.Cout % 4 != 0) return fail(UDP_ERR_UNSUPPORTED, "fuse Cout=%d is not a multiple of 4", p.Cout);
   const long total = (long)p.N * p.Hout * p.Wout * (p.Cout / 4);
   long blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  if (dtype == UDP_F32)
-    hipLaunchKernelGGL(fuse_sum_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, p);
-  else
-    hipLaunchKernelGGL(fuse_sum_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, s, p);
-  UDP_HIP_CHECK(hipGetLastError());
+  out->fn = dtype == UDP_F32 ? reinterpret_cast<const void*>(&fuse_sum_kernel<float>)
+                             : reinterpret_cast<const void*>(&fuse_sum_kernel<__bf16>);
+  out->grid = dim3((unsigned)blocks);
+  out->block = dim3(256);
+  out->lds = 0;
+  out->p = p;
+  return UDP_OK;
+}
+
+int run_launch(const Launch& l, hipStream_t s) {
+  void* args[] = {const_cast<ConvParams*>(&l.p)};
+  UDP_HIP_CHECK(hipLaunchKernel(l.fn, l.grid, l.block, args, l.lds, s));
   return UDP_OK;
 }
 

@@ -2,15 +2,16 @@
 // (include/udp_pose_hip.h, udp_conv_op) on one HIP stream, optionally replaying
 // it as a hipGraph.  Replaces PoseHighResolutionNet.forward,
 // deep_hrnet/lib/models/pose_hrnet.py:436-471.
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
 
 namespace udp {
-size_t conv_choose_tile(ConvParams& p, int ks, int stride, int dtype, int* nb_out);
-int launch_conv(const ConvParams& p, int dtype, int ks, int stride, int nb, size_t lds, hipStream_t s);
-int launch_stem(const ConvParams& p, int dtype, hipStream_t s);
-int launch_fuse(const ConvParams& p, int dtype, hipStream_t s);
+int describe_conv(ConvParams p, int dtype, int ks, int stride, Launch* out);
+int describe_stem(const ConvParams& p, int dtype, Launch* out);
+int describe_fuse(const ConvParams& p, int dtype, Launch* out);
+int run_launch(const Launch& l, hipStream_t s);
 }  // namespace udp
 
 using namespace udp;
@@ -35,6 +36,12 @@ struct udp_hrnet {
   int in_h = 0, in_w = 0, out_channels = 0;
   double flops = 0.0;
   std::vector<GraphEntry> graphs;
+  // branch-parallel execution: lane 0 = caller's stream, lanes 1.. = internal streams
+  int n_lanes = 1;
+  hipStream_t lane_stream[UDP_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+  std::vector<hipEvent_t> op_done;     // one per op (recorded only where another lane waits on it)
+  std::vector<char> op_signals;        // op has a cross-lane consumer
+  hipEvent_t ev_fork = nullptr, ev_join[UDP_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 static size_t esize(int dtype) { return dtype == UDP_F32 ? 4 : 2; }
@@ -75,6 +82,9 @@ static int validate_op(const udp_hrnet* h, const udp_conv_op& o, int idx) {
   } else if (o.hin != o.hout || o.win != o.wout || o.cin != o.cout) {
     return fail(UDP_ERR_ARG, "op %d: fuse op must keep the shape", idx);
   }
+  if (o.lane < 0 || o.lane >= UDP_MAX_LANES || o.n_wait < 0 || o.n_wait > UDP_MAX_WAIT) return fail(UDP_ERR_ARG, "op %d: lane/n_wait", idx);
+  for (int k = 0; k < o.n_wait; ++k)
+    if (o.wait_op[k] < 0 || o.wait_op[k] >= idx) return fail(UDP_ERR_ARG, "op %d: wait_op %d must name an earlier op", idx, o.wait_op[k]);
   if (o.res_buf != UDP_BUF_NONE && !buf_ok(o.res_buf, out_need)) return fail(UDP_ERR_ARG, "op %d: res_buf", idx);
   if (o.n_up < 0 || o.n_up > 3) return fail(UDP_ERR_ARG, "op %d: n_up", idx);
   for (int u = 0; u < o.n_up; ++u) {
@@ -128,9 +138,26 @@ extern "C" int udp_hrnet_create(const udp_conv_op* ops, int n_ops, const int64_t
       h->flops += 2.0 * ops[i].ks * ops[i].ks * ops[i].cin * ops[i].cout * ops[i].hout * ops[i].wout;
     h->ops.push_back(ops[i]);
   }
-  if (!has_out || h->ops[0].kind != UDP_OP_STEM) {
+  if (!has_out || h->ops[0].kind != UDP_OP_STEM || h->ops[0].lane != 0 || h->ops.back().lane != 0 ||
+      h->ops.back().out_buf != UDP_BUF_OUTPUT) {
     delete h;
-    return fail(UDP_ERR_ARG, "udp_hrnet_create: program needs a stem op first and an output op");
+    return fail(UDP_ERR_ARG, "udp_hrnet_create: program needs a stem op first and the output op last, both on lane 0");
+  }
+  h->op_signals.assign(n_ops, 0);
+  for (int i = 0; i < n_ops; ++i) {
+    if (ops[i].lane + 1 > h->n_lanes) h->n_lanes = ops[i].lane + 1;
+    for (int k = 0; k < ops[i].n_wait; ++k) h->op_signals[ops[i].wait_op[k]] = 1;
+  }
+  h->op_done.assign(n_ops, nullptr);
+  hipError_t e = hipSuccess;
+  for (int l = 1; l < h->n_lanes && e == hipSuccess; ++l) e = hipStreamCreateWithFlags(&h->lane_stream[l], hipStreamNonBlocking);
+  for (int l = 1; l < h->n_lanes && e == hipSuccess; ++l) e = hipEventCreateWithFlags(&h->ev_join[l], hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+  for (int i = 0; i < n_ops && e == hipSuccess; ++i)
+    if (h->op_signals[i]) e = hipEventCreateWithFlags(&h->op_done[i], hipEventDisableTiming);
+  if (e != hipSuccess) {
+    udp_hrnet_destroy(h);
+    return fail(UDP_ERR_HIP, "udp_hrnet_create: stream/event creation failed: %s", hipGetErrorString(e));
   }
   *out = h;
   return UDP_OK;
@@ -144,11 +171,13 @@ extern "C" size_t udp_hrnet_workspace_bytes(const udp_hrnet* h, int n, int flip_
 extern "C" int udp_hrnet_num_launches(const udp_hrnet* h) { return h ? (int)h->ops.size() : 0; }
 extern "C" double udp_hrnet_flops_per_image(const udp_hrnet* h) { return h ? h->flops : 0.0; }
 
-static int enqueue_all(udp_hrnet* h, const float* in, int n, int flip, char* ws, float* out, hipStream_t s,
-                       hipEvent_t* ev = nullptr) {
+// Resolves buffers / weights of every op for this call and picks kernels + tiles.
+static int describe_all(const udp_hrnet* h, const float* in, int n, int flip, char* ws, float* out,
+                        std::vector<Launch>& ls) {
   const int B = n * (flip ? 2 : 1);
   const size_t es = esize(h->dtype);
   auto buf = [&](int b) -> char* { return ws + (size_t)h->buf_off[b] * B * es; };
+  ls.resize(h->ops.size());
   for (size_t i = 0; i < h->ops.size(); ++i) {
     const udp_conv_op& o = h->ops[i];
     ConvParams p;
@@ -177,32 +206,114 @@ static int enqueue_all(udp_hrnet* h, const float* in, int n, int flip, char* ws,
       p.bias = reinterpret_cast<const float*>(h->weights + o.b_off);
     }
     int rc;
-    if (ev) UDP_HIP_CHECK(hipEventRecord(ev[2 * i], s));
-    if (o.kind == UDP_OP_STEM) {
-      rc = launch_stem(p, h->dtype, s);
-    } else if (o.kind == UDP_OP_FUSE) {
-      rc = launch_fuse(p, h->dtype, s);
-    } else {
-      int nb = 2;
-      const size_t lds = conv_choose_tile(p, o.ks, o.stride, h->dtype, &nb);
-      rc = launch_conv(p, h->dtype, o.ks, o.stride, nb, lds, s);
-    }
+    if (o.kind == UDP_OP_STEM)
+      rc = describe_stem(p, h->dtype, &ls[i]);
+    else if (o.kind == UDP_OP_FUSE)
+      rc = describe_fuse(p, h->dtype, &ls[i]);
+    else
+      rc = describe_conv(p, h->dtype, o.ks, o.stride, &ls[i]);
     if (rc) return rc;
-    if (ev) UDP_HIP_CHECK(hipEventRecord(ev[2 * i + 1], s));
   }
+  return UDP_OK;
+}
+
+// Eager execution.  lanes != 0: ops run on their lane's stream (lane 0 = s) with event edges for
+// the cross-lane dependencies the host planner listed, forked from / joined back into s.
+// ev != null: serial on s with an event pair around every op (profiling).
+static int enqueue_all(udp_hrnet* h, const std::vector<Launch>& L, hipStream_t s, hipEvent_t* ev, int lanes) {
+  lanes = lanes && h->n_lanes > 1 && !ev && getenv("UDP_POSE_SERIAL") == nullptr;
+  hipStream_t ls[UDP_MAX_LANES] = {s, s, s, s};
+  if (lanes) {
+    UDP_HIP_CHECK(hipEventRecord(h->ev_fork, s));
+    for (int l = 1; l < h->n_lanes; ++l) {
+      ls[l] = h->lane_stream[l];
+      UDP_HIP_CHECK(hipStreamWaitEvent(ls[l], h->ev_fork, 0));
+    }
+  }
+  for (size_t i = 0; i < h->ops.size(); ++i) {
+    const udp_conv_op& o = h->ops[i];
+    hipStream_t os = ls[o.lane];
+    if (lanes)
+      for (int k = 0; k < o.n_wait; ++k)
+        if (h->ops[o.wait_op[k]].lane != o.lane) UDP_HIP_CHECK(hipStreamWaitEvent(os, h->op_done[o.wait_op[k]], 0));
+    if (ev) UDP_HIP_CHECK(hipEventRecord(ev[2 * i], os));
+    const int rc = run_launch(L[i], os);
+    if (rc) return rc;
+    if (ev) UDP_HIP_CHECK(hipEventRecord(ev[2 * i + 1], os));
+    if (lanes && h->op_signals[i]) UDP_HIP_CHECK(hipEventRecord(h->op_done[i], os));
+  }
+  if (lanes)
+    for (int l = 1; l < h->n_lanes; ++l) {
+      UDP_HIP_CHECK(hipEventRecord(h->ev_join[l], ls[l]));
+      UDP_HIP_CHECK(hipStreamWaitEvent(s, h->ev_join[l], 0));
+    }
+  return UDP_OK;
+}
+
+// hipGraph of the same program: one kernel node per op; edges = previous op of the same lane +
+// the planner's cross-lane dependencies, so independent HRNet branches overlap on the GPU.
+static int build_graph(udp_hrnet* h, const std::vector<Launch>& L, hipGraph_t* graph, hipGraphExec_t* exec) {
+  UDP_HIP_CHECK(hipGraphCreate(graph, 0));
+  std::vector<hipGraphNode_t> node(L.size());
+  int last_on_lane[UDP_MAX_LANES] = {-1, -1, -1, -1};
+  const bool serial = getenv("UDP_POSE_SERIAL") != nullptr;   // debugging aid: one chain, no branch overlap
+  for (size_t i = 0; i < L.size(); ++i) {
+    const udp_conv_op& o = h->ops[i];
+    std::vector<hipGraphNode_t> deps;
+    if (serial) {
+      if (i) deps.push_back(node[i - 1]);
+    } else {
+      if (last_on_lane[o.lane] >= 0) deps.push_back(node[last_on_lane[o.lane]]);
+      for (int k = 0; k < o.n_wait; ++k) deps.push_back(node[o.wait_op[k]]);
+    }
+    ConvParams p = L[i].p;
+    void* args[] = {&p};
+    hipKernelNodeParams kp;
+    memset(&kp, 0, sizeof(kp));
+    kp.func = const_cast<void*>(L[i].fn);
+    kp.gridDim = L[i].grid;
+    kp.blockDim = L[i].block;
+    kp.sharedMemBytes = L[i].lds;
+    kp.kernelParams = args;
+    kp.extra = nullptr;
+    hipError_t e = hipGraphAddKernelNode(&node[i], *graph, deps.data(), deps.size(), &kp);
+    if (e != hipSuccess) {
+      (void)hipGraphDestroy(*graph);
+      return fail(UDP_ERR_HIP, "hipGraphAddKernelNode(op %zu): %s", i, hipGetErrorString(e));
+    }
+    last_on_lane[o.lane] = (int)i;
+  }
+  hipError_t e = hipGraphInstantiate(exec, *graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    (void)hipGraphDestroy(*graph);
+    return fail(UDP_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+  }
+  return UDP_OK;
+}
+
+static int check_forward_args(const char* who, const udp_hrnet* h, const float* in, int n, int flip, const void* ws,
+                              size_t ws_bytes, const float* out) {
+  if (!h || !in || !ws || !out) return fail(UDP_ERR_ARG, "%s: null pointer", who);
+  if (n <= 0) return fail(UDP_ERR_ARG, "%s: n=%d (the reference engine also requires n >= 1)", who, n);
+  if (ws_bytes < udp_hrnet_workspace_bytes(h, n, flip))
+    return fail(UDP_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", who, ws_bytes, udp_hrnet_workspace_bytes(h, n, flip));
+  if (reinterpret_cast<uintptr_t>(ws) & 255) return fail(UDP_ERR_ARG, "%s: workspace not 256-byte aligned", who);
   return UDP_OK;
 }
 
 extern "C" int udp_hrnet_profile(udp_hrnet* h, const float* in_nchw, int n, int flip_test, void* workspace,
                                  size_t workspace_bytes, float* heatmaps_nchw, float* ms_per_op, void* stream) {
-  if (!h || !in_nchw || !workspace || !heatmaps_nchw || !ms_per_op) return fail(UDP_ERR_ARG, "udp_hrnet_profile: null pointer");
-  if (n <= 0) return fail(UDP_ERR_ARG, "udp_hrnet_profile: n=%d", n);
-  if (workspace_bytes < udp_hrnet_workspace_bytes(h, n, flip_test)) return fail(UDP_ERR_WORKSPACE, "udp_hrnet_profile: workspace too small");
+  int rc = check_forward_args("udp_hrnet_profile", h, in_nchw, n, flip_test, workspace, workspace_bytes, heatmaps_nchw);
+  if (rc) return rc;
+  if (!ms_per_op) return fail(UDP_ERR_ARG, "udp_hrnet_profile: null pointer");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  std::vector<Launch> L;
+  rc = describe_all(h, in_nchw, n, flip_test ? 1 : 0, reinterpret_cast<char*>(workspace), heatmaps_nchw, L);
+  if (rc) return rc;
   const size_t nops = h->ops.size();
   std::vector<hipEvent_t> ev(2 * nops);
   for (auto& e : ev) UDP_HIP_CHECK(hipEventCreate(&e));
-  int rc = enqueue_all(h, in_nchw, n, flip_test ? 1 : 0, reinterpret_cast<char*>(workspace), heatmaps_nchw, s, ev.data());
+  rc = enqueue_all(h, L, s, ev.data(), 0);
   hipError_t se = hipStreamSynchronize(s);
   if (!rc && se == hipSuccess)
     for (size_t i = 0; i < nops; ++i)
@@ -215,47 +326,36 @@ extern "C" int udp_hrnet_profile(udp_hrnet* h, const float* in_nchw, int n, int 
 
 extern "C" int udp_hrnet_forward(udp_hrnet* h, const float* in_nchw, int n, int flip_test, void* workspace,
                                  size_t workspace_bytes, float* heatmaps_nchw, int use_graph, void* stream) {
-  if (!h || !in_nchw || !workspace || !heatmaps_nchw) return fail(UDP_ERR_ARG, "udp_hrnet_forward: null pointer");
-  if (n <= 0) return fail(UDP_ERR_ARG, "udp_hrnet_forward: n=%d (the reference engine also requires n >= 1)", n);
-  if (workspace_bytes < udp_hrnet_workspace_bytes(h, n, flip_test))
-    return fail(UDP_ERR_WORKSPACE, "udp_hrnet_forward: workspace %zu < %zu bytes", workspace_bytes,
-                udp_hrnet_workspace_bytes(h, n, flip_test));
-  if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(UDP_ERR_ARG, "udp_hrnet_forward: workspace not 256-byte aligned");
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  char* ws = reinterpret_cast<char*>(workspace);
-  flip_test = flip_test ? 1 : 0;
-  if (!use_graph) return enqueue_all(h, in_nchw, n, flip_test, ws, heatmaps_nchw, s);
-
-  for (auto& g : h->graphs)
-    if (g.n == n && g.flip == flip_test && g.in == in_nchw && g.ws == workspace && g.out == heatmaps_nchw) {
-      UDP_HIP_CHECK(hipGraphLaunch(g.exec, s));
-      return UDP_OK;
-    }
-  // First call for this (shape, buffers): run eagerly (also sets per-kernel attributes), then
-  // capture the same launch sequence for the following calls.
-  int rc = enqueue_all(h, in_nchw, n, flip_test, ws, heatmaps_nchw, s);
+  int rc = check_forward_args("udp_hrnet_forward", h, in_nchw, n, flip_test, workspace, workspace_bytes, heatmaps_nchw);
   if (rc) return rc;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  flip_test = flip_test ? 1 : 0;
+  if (use_graph)
+    for (auto& g : h->graphs)
+      if (g.n == n && g.flip == flip_test && g.in == in_nchw && g.ws == workspace && g.out == heatmaps_nchw) {
+        UDP_HIP_CHECK(hipGraphLaunch(g.exec, s));
+        return UDP_OK;
+      }
+  std::vector<Launch> L;
+  rc = describe_all(h, in_nchw, n, flip_test, reinterpret_cast<char*>(workspace), heatmaps_nchw, L);
+  if (rc) return rc;
+  if (!use_graph) return enqueue_all(h, L, s, nullptr, 1);
+  // First call for this (shape, buffers): build the graph, then launch it.
   GraphEntry e;
   e.n = n;
   e.flip = flip_test;
   e.in = in_nchw;
   e.ws = workspace;
   e.out = heatmaps_nchw;
-  hipStream_t cs;
-  UDP_HIP_CHECK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-  UDP_HIP_CHECK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
-  rc = enqueue_all(h, in_nchw, n, flip_test, ws, heatmaps_nchw, cs);
-  hipError_t ce = hipStreamEndCapture(cs, &e.graph);
-  (void)hipStreamDestroy(cs);
+  rc = build_graph(h, L, &e.graph, &e.exec);
   if (rc) return rc;
-  if (ce != hipSuccess) return fail(UDP_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
-  UDP_HIP_CHECK(hipGraphInstantiate(&e.exec, e.graph, nullptr, nullptr, 0));
   if (h->graphs.size() >= 8) {
     (void)hipGraphExecDestroy(h->graphs[0].exec);
     (void)hipGraphDestroy(h->graphs[0].graph);
     h->graphs.erase(h->graphs.begin());
   }
   h->graphs.push_back(e);
+  UDP_HIP_CHECK(hipGraphLaunch(e.exec, s));
   return UDP_OK;
 }
 
@@ -265,6 +365,13 @@ extern "C" int udp_hrnet_destroy(udp_hrnet* h) {
     (void)hipGraphExecDestroy(g.exec);
     (void)hipGraphDestroy(g.graph);
   }
+  for (int l = 1; l < UDP_MAX_LANES; ++l) {
+    if (h->lane_stream[l]) (void)hipStreamDestroy(h->lane_stream[l]);
+    if (h->ev_join[l]) (void)hipEventDestroy(h->ev_join[l]);
+  }
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  for (auto e : h->op_done)
+    if (e) (void)hipEventDestroy(e);
   delete h;
   return UDP_OK;
 }
@@ -313,8 +420,8 @@ extern "C" int udp_conv2d_fused(const udp_conv_op* o, int dtype, int n, const vo
     p.up_shift[u] = s;
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  if (o->kind == UDP_OP_FUSE) return launch_fuse(p, dtype, s);
-  int nb = 2;
-  const size_t lds = conv_choose_tile(p, o->ks, o->stride, dtype, &nb);
-  return launch_conv(p, dtype, o->ks, o->stride, nb, lds, s);
+  Launch l;
+  const int rc = o->kind == UDP_OP_FUSE ? describe_fuse(p, dtype, &l) : describe_conv(p, dtype, o->ks, o->stride, &l);
+  if (rc) return rc;
+  return run_launch(l, s);
 }

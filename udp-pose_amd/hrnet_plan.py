@@ -208,28 +208,62 @@ class HRNetProgram:
             outs.append(t)
         return outs
 
-    # ------------------------------------------------------------------ buffers
+    # ------------------------------------------------------------------ lanes + buffers
     def _assign_buffers(self):
-        last_use = {}
+        """Linear-scan buffer assignment plus the cross-lane dependency lists.
+
+        Lane = resolution level of the op's output (HRNet branch): ops of different lanes may run
+        concurrently, ordered only by (a) producer -> consumer edges and (b) buffer reuse: the new
+        writer of a physical buffer waits for the previous tenant's writer and readers.  Same-lane
+        predecessors are ordered by the stream itself and are not listed."""
+        h4 = self.in_h // 4
+        for op in self._ops:
+            lvl = 0
+            while (h4 >> lvl) > op["hout"] and lvl < _lib.MAX_LANES - 1:
+                lvl += 1
+            op["lane"] = lvl
+        self._ops[0]["lane"] = 0
+        producer = {}
+        readers = {}
         for idx, op in enumerate(self._ops):
+            if op["out"] is not None:
+                producer[op["out"].id] = idx
             for t in [op["inp"], op["res"]] + [u for u, _ in op["ups"]]:
                 if t is not None:
-                    last_use[t.id] = idx
-        free = {}             # elems -> [buffer ids]
+                    readers.setdefault(t.id, []).append(idx)
+        last_use = {tid: max(r) for tid, r in readers.items()}
+        free = {}             # elems -> [(buffer id, previous tenant tensor id)]
         self.buf_elems = []
         phys = {}
         for idx, op in enumerate(self._ops):
+            deps = set()
+            for t in [op["inp"], op["res"]] + [u for u, _ in op["ups"]]:
+                if t is not None and t.id in producer:
+                    deps.add(producer[t.id])
             out = op["out"]
             if out is not None:
-                pool = free.get(out.elems)
-                if pool:
-                    phys[out.id] = pool.pop()
+                pool = free.get(out.elems, [])
+                pick = None
+                for k in range(len(pool) - 1, -1, -1):
+                    b, old = pool[k]
+                    hazard = {producer[old]} | set(readers.get(old, []))
+                    cross = {d for d in (deps | hazard) if self._ops[d]["lane"] != op["lane"]}
+                    if len(cross) <= _lib.MAX_WAIT:
+                        pick = k
+                        deps |= hazard
+                        break
+                if pick is not None:
+                    phys[out.id] = pool.pop(pick)[0]
                 else:
                     phys[out.id] = len(self.buf_elems)
                     self.buf_elems.append(out.elems)
+            cross = sorted(d for d in deps if self._ops[d]["lane"] != op["lane"])
+            if len(cross) > _lib.MAX_WAIT:
+                raise RuntimeError("op %s has %d cross-lane dependencies (max %d)" % (op["name"], len(cross), _lib.MAX_WAIT))
+            op["wait"] = cross
             for t in [op["inp"], op["res"]] + [u for u, _ in op["ups"]]:
                 if t is not None and last_use.get(t.id) == idx and t.id in phys:
-                    free.setdefault(t.elems, []).append(phys[t.id])
+                    free.setdefault(t.elems, []).append((phys[t.id], t.id))
                     last_use[t.id] = -1
         self._phys = phys
 
@@ -244,6 +278,10 @@ class HRNetProgram:
             o.in_buf = _lib.UDP_BUF_NONE if op["inp"] is None else self._phys[op["inp"].id]
             o.out_buf = _lib.UDP_BUF_OUTPUT if op["out"] is None else self._phys[op["out"].id]
             o.res_buf = _lib.UDP_BUF_NONE if op["res"] is None else self._phys[op["res"].id]
+            o.lane = op["lane"]
+            o.n_wait = len(op["wait"])
+            for k, d in enumerate(op["wait"]):
+                o.wait_op[k] = d
             o.n_up = len(op["ups"])
             for u, (t, s) in enumerate(op["ups"]):
                 o.up_buf[u] = self._phys[t.id]
