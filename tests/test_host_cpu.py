@@ -90,3 +90,36 @@ def test_yaml_config_defaults(tmp_path):
     cfg = load_config(str(p))
     assert cfg.MODEL.TARGET_TYPE == "offset" and cfg.LOSS.KPD == 4.0 and cfg.TEST.POST_PROCESS is True
     assert cfg["MODEL"]["EXTRA"]["FINAL_CONV_KERNEL"] == 1 and cfg.MODEL.NUM_JOINTS == 17
+
+
+def test_lanes_order_every_buffer_hazard():
+    """Branch lanes may overlap on the GPU: every RAW / WAR / WAW pair on a physical buffer must be
+    ordered by (previous op on the same lane) + (the op's cross-lane wait list), transitively."""
+    sd = synth.synth_state_dict(synth.W32_EXTRA, 17, "gaussian", seed=0)
+    ops = hrnet_plan.HRNetProgram(sd, synth.W32_EXTRA, 256, 192, "bf16").ops_array()
+    n = len(ops)
+    hb = [0] * n                      # bitset of ops that happen before op i
+    last = {}
+    for i, o in enumerate(ops):
+        m = 0
+        preds = [o.wait_op[k] for k in range(o.n_wait)] + ([last[o.lane]] if o.lane in last else [])
+        for j in preds:
+            assert j < i
+            m |= hb[j] | (1 << j)
+        hb[i] = m
+        last[o.lane] = i
+    assert {o.lane for o in ops} == {0, 1, 2, 3} and ops[0].lane == 0 and ops[n - 1].lane == 0
+    touched = {}
+    for i, o in enumerate(ops):
+        reads = [b for b in [o.in_buf, o.res_buf] + [o.up_buf[u] for u in range(o.n_up)] if b >= 0]
+        writes = [o.out_buf] if o.out_buf >= 0 else []
+        for b in reads:
+            for j, kind in touched.get(b, []):
+                assert kind == "r" or (hb[i] >> j) & 1, "unordered RAW on buffer %d: op %d -> %d" % (b, j, i)
+        for b in writes:
+            for j, kind in touched.get(b, []):
+                assert (hb[i] >> j) & 1, "unordered WA%s on buffer %d: op %d -> %d" % (kind.upper(), b, j, i)
+        for b in reads:
+            touched.setdefault(b, []).append((i, "r"))
+        for b in writes:
+            touched.setdefault(b, []).append((i, "w"))

@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
 // :437-439.  Images n >= flip_from read image n - flip_from mirrored along W
 // (flip-test second pass, function.py:154-156).
 template <typename T>
-__global__ __launch_bounds__(256) void stem_conv_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, 4) void stem_conv_kernel(const ConvParams p) {
   __shared__ __attribute__((aligned(16))) float w_s[27 * 64];
   __shared__ __attribute__((aligned(16))) float b_s[64];
   const int tid = threadIdx.x;
@@ -358,26 +358,24 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const ConvParams p) {
   float acc[16];
 #pragma unroll
   for (int q = 0; q < 16; ++q) acc[q] = b_s[cg * 16 + q];
-#pragma unroll
-  for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll 1
+  for (int tap = 0; tap < 9; ++tap) {   // rolled on purpose: a full unroll needs > 256 VGPRs
+    const int ky = tap / 3, kx = tap - ky * 3;
     const int gy = yo * 2 - 1 + ky;
+    const int gx = xo * 2 - 1 + kx;
+    const bool ok = gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win;
+    const int sx = mirror ? p.Win - 1 - gx : gx;
+    const float* wr = &w_s[tap * 3 * 64 + cg * 16];
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      const int gx = xo * 2 - 1 + kx;
-      const bool ok = gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win;
-      const int sx = mirror ? p.Win - 1 - gx : gx;
+    for (int ci = 0; ci < 3; ++ci) {
+      const float v = ok ? in[((size_t)ci * p.Hin + gy) * p.Win + sx] : 0.f;
 #pragma unroll
-      for (int ci = 0; ci < 3; ++ci) {
-        const float v = ok ? in[((size_t)ci * p.Hin + gy) * p.Win + sx] : 0.f;
-        const float* wr = &w_s[((ky * 3 + kx) * 3 + ci) * 64 + cg * 16];
-#pragma unroll
-        for (int q = 0; q < 16; q += 4) {
-          const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + q);
-          acc[q + 0] = fmaf(v, w4[0], acc[q + 0]);
-          acc[q + 1] = fmaf(v, w4[1], acc[q + 1]);
-          acc[q + 2] = fmaf(v, w4[2], acc[q + 2]);
-          acc[q + 3] = fmaf(v, w4[3], acc[q + 3]);
-        }
+      for (int q = 0; q < 16; q += 4) {
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + ci * 64 + q);
+        acc[q + 0] = fmaf(v, w4[0], acc[q + 0]);
+        acc[q + 1] = fmaf(v, w4[1], acc[q + 1]);
+        acc[q + 2] = fmaf(v, w4[2], acc[q + 2]);
+        acc[q + 3] = fmaf(v, w4[3], acc[q + 3]);
       }
     }
   }
