@@ -105,9 +105,17 @@ def roofline(net, hp, steps, dtype):
     achieved = flops / (t_ms * 1e-3) / 1e12
     table = {k: {"ms": round(v[0], 4), "launches": v[3], "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 2) if v[0] > 0 else 0,
                  "gbs": round(v[2] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else 0} for k, v in classes.items()}
+    traffic = None      # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/pmc_by_op.py)
+    tfile = os.path.join(ROOT, "profiles", "r01b_traffic_%s.json" % dtype)
+    if os.path.exists(tfile) and hp.n == 64:
+        with open(tfile) as f:
+            tc = json.load(f)["classes"].get(dom)
+        if tc:
+            traffic = round(tc["hbm_bytes_per_launch"], 0)
     return {"bound": "mfma", "kernel": "conv_mfma_kernel<%s> %s" % (dtype, dom), "achieved": round(achieved, 2),
             "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS[dtype], 4),
-            "traffic": None, "launches_per_step": cnt, "avg_launch_us": round(t_ms / cnt * 1e3, 2),
+            "traffic": traffic, "traffic_source": os.path.basename(tfile) if traffic else None,
+            "launches_per_step": cnt, "avg_launch_us": round(t_ms / cnt * 1e3, 2),
             "algorithmic_gflop_per_launch": round(flops / cnt / 1e9, 3),
             "algorithmic_gbs_same_kernel": round(byts / (t_ms * 1e-3) / 1e9, 1),
             "sum_kernel_ms_per_step": round(float(ms.sum()), 3), "classes": table}
