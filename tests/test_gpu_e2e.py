@@ -104,7 +104,7 @@ def test_w32_flip_test_and_decode_end_to_end(w32_gaussian):
     hp, hmv, _, hidx = odec.get_final_preds("gaussian", True, 4.0, hm.cpu().numpy().copy(), c, s)
     np.testing.assert_array_equal(idx.cpu().numpy(), hidx)
     hgood = _dark_shift(hm.cpu().numpy()) < 1.5
-    np.testing.assert_allclose(preds.cpu().numpy()[hgood], hp[hgood], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(preds.cpu().numpy()[hgood], hp[hgood], rtol=0, atol=1e-3)   # north-star tolerance
     np.testing.assert_allclose(preds.cpu().numpy(), hp, rtol=5e-3, atol=1e-3)   # ill-conditioned Hessians
     # (b) whole pipeline vs the oracle pipeline.  DARK solves H^-1 D on second differences of a
     # log map, so 1e-5 heat-map noise is amplified by 1/|H|: compare where the oracle's own Taylor

@@ -48,7 +48,7 @@ struct ConvParams {
   int IH, IW;            // input halo tile per image
   int tiles_x, tiles_y;  // tiles per image group
   int ntiles;            // all tiles of the launch (persistent workgroups stride over them)
-  unsigned mIW, mIH, mRT, mTW;  // ceil(2^32/d) (0 for d == 1): x/d == umulhi(x, m) for x < 65536
+  unsigned mIW, mIH, mRT, mTW;  // ceil(2^20/d): x/d == (x*m) >> 20 for x*d < 2^20 (24-bit multiply)
   int relu;
   int out_nchw_f32;      // epilogue writes NCHW fp32 (network output) instead of NHWC T
   int flip_from;         // stem only: images >= flip_from read image (n - flip_from) mirrored in x

@@ -22,6 +22,7 @@
 // one pixel -> 16-byte NHWC stores / residual loads in the epilogue.
 //   fp32 : v_mfma_f32_16x16x4_f32  (exact fp32 fma chain), ds_read_b64 feeds 2 MFMAs
 //   bf16 : v_mfma_f32_16x16x32_bf16 (fp32 accumulate),     ds_read_b128 feeds 1 MFMA
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -36,18 +37,8 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int ROWB = 64;   // LDS row: one pixel's (or one weight row's) 64-byte channel chunk
 constexpr int MAXG = 10;   // 16-row staging groups per wave for the input tile (<= 640 rows)
 
-__device__ uint4 g_zero_row[4];   // 64 zero bytes: DMA source for halo rows outside the image
-
 // 16-byte part p of LDS row r is stored at part position p ^ swz(r)
 __device__ __forceinline__ int swz(int row) { return (-(row >> 2)) & 3; }
-
-// x / d for x < 65536 with m = ceil(2^32 / d)
-__device__ __forceinline__ int fdiv(int x, unsigned m) { return m ? (int)__umulhi((unsigned)x, m) : x; }   // m == 0 <=> d == 1
-
-__device__ __forceinline__ void glds16(const char* src, unsigned char* lds_wave_base) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
 
 template <typename T>
 struct Tr;
@@ -120,9 +111,64 @@ __device__ __forceinline__ void store_vec(T* p, const f32x4 (&v)[NB]) {
   }
 }
 
-template <typename T, int KS, int STRIDE, int NB>
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOobOff = 0x7FFF0000u;   // voffset of a masked lane: beyond every buffer (< 2 GiB), no wrap with + small
+
+// x / d for x*d < 2^20 with m = ceil(2^20 / d): one full-rate 24-bit multiply and a shift
+__device__ __forceinline__ int fdiv20(int x, unsigned m) { return (int)(__umul24((unsigned)x, m) >> 20); }
+
+// LDS-DMA through a buffer descriptor: SGPR base + 32-bit per-lane offset; lanes whose offset is out
+// of range get ZEROS written to LDS (checked on MI355X: tools/micro/bl_lds.hip) -> conv zero padding
+__device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, 0, 0, 0);
+}
+
+// 4*NB consecutive channels of one pixel <-> the NB accumulator tiles of a lane, through a buffer
+// descriptor: masked lanes pass kOobOff (loads return 0, stores are dropped) -> no branches
+template <typename T, int NB>
+__device__ __forceinline__ void add_vec_buf(f32x4 (&v)[NB], __amdgpu_buffer_rsrc_t r, unsigned voff) {
+  if constexpr (std::is_same<T, float>::value) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+      v[nb] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff + 16 * nb, 0, 0));
+  } else {
+#pragma unroll
+    for (int h = 0; h < NB / 2; ++h) {
+      const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(r, voff + 16 * h, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const unsigned wlo = x[q >> 1], whi = x[2 + (q >> 1)];
+        v[2 * h][q] += __builtin_bit_cast(float, (q & 1) ? (wlo & 0xFFFF0000u) : (wlo << 16));
+        v[2 * h + 1][q] += __builtin_bit_cast(float, (q & 1) ? (whi & 0xFFFF0000u) : (whi << 16));
+      }
+    }
+  }
+}
+template <typename T, int NB>
+__device__ __forceinline__ void store_vec_buf(__amdgpu_buffer_rsrc_t r, unsigned voff, const f32x4 (&v)[NB]) {
+  if constexpr (std::is_same<T, float>::value) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[nb]), r, voff + 16 * nb, 0, 0);
+  } else {
+#pragma unroll
+    for (int h = 0; h < NB / 2; ++h) {
+      bf16x8 o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        o[q] = (__bf16)v[2 * h][q];
+        o[4 + q] = (__bf16)v[2 * h + 1][q];
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), r, voff + 16 * h, 0, 0);
+    }
+  }
+}
+
+// MBW = 16-pixel blocks per wave (ceil(M/64)); NCHW = epilogue writes the fp32 NCHW network output.
+template <typename T, int KS, int STRIDE, int NB, int MBW, bool NCHW>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
   constexpr int CK = Tr<T>::CK;
+  constexpr int ESZ = (int)sizeof(T);
   constexpr int BN = NB * 16;
   constexpr int PAD = KS / 2;
   constexpr int TAPS = KS * KS;
@@ -135,12 +181,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
   const int li = lane & 15;
   const int kg = lane >> 4;
 
-  int t = blockIdx.x;   // wave-uniform: plain division (t may exceed the 16-bit range of fdiv)
+  int t = blockIdx.x;   // wave-uniform tile decode
   const int tx = t % p.tiles_x;
   t /= p.tiles_x;
   const int ty = t % p.tiles_y;
-  t /= p.tiles_y;
-  const int n0 = t * p.G;
+  const int n0 = (t / p.tiles_y) * p.G;
   const int y0 = ty * p.R;
   const int x0 = tx * p.TW;
   const int cb = blockIdx.y;
@@ -151,77 +196,91 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
   const int in_bytes = in_groups * 16 * ROWB;
   const int stage_bytes = in_bytes + TAPS * BN * ROWB;
   const int nchunks = p.Cin / CK;
-
   const int RT = p.R * p.TW;
   const int M = p.G * RT;
-  const int nmb = (M + 15) >> 4;
+  const unsigned cinb = (unsigned)p.Cin * ESZ;
 
-  const char* in_base = reinterpret_cast<const char*>(p.in);
-  const char* w_base = reinterpret_cast<const char*>(p.wgt);
-  const char* zero = reinterpret_cast<const char*>(g_zero_row);
+  const unsigned out_pix = (unsigned)p.N * p.Hout * p.Wout;
+  const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.in), 0, (unsigned)p.N * p.Hin * p.Win * cinb, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.wgt), 0, (unsigned)TAPS * p.CoutPad * cinb, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(
+      p.out, 0, out_pix * p.Cout * (NCHW ? 4 : ESZ), 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.res), 0, p.res ? out_pix * p.Cout * ESZ : 0, 0x00020000);
 
-  // ---- per-lane DMA sources of the input halo tile (same for every chunk)
+  // ---- per-lane DMA offsets of the input halo tile (chunk 0); masked rows -> kOobOff -> zeros
   const int srow = lane >> 2;  // row inside a 16-row group
   const int spart = lane & 3;  // stored 16-byte part position
-  int src_off[MAXG];           // byte offset of (pixel, chunk 0, logical part), -1 = zero row (tensors < 2 GiB)
+  const int gy0 = y0 * STRIDE - PAD, gx0 = x0 * STRIDE - PAD;
+  unsigned src_off[MAXG];
 #pragma unroll
   for (int i = 0; i < MAXG; ++i) {
-    const int row = (wave + 4 * i) * 16 + srow;
-    int off = -1;
-    if (row < npix_in) {
-      const int tmp = fdiv(row, p.mIW);
-      const int ix = row - tmp * IW;
-      const int g = fdiv(tmp, p.mIH);
-      const int iy = tmp - g * IH;
-      const int n = n0 + g;
-      const int gy = y0 * STRIDE - PAD + iy;
-      const int gx = x0 * STRIDE - PAD + ix;
-      if (n < p.N && gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win)
-        off = (((n * p.Hin + gy) * p.Win + gx) * p.Cin) * (int)sizeof(T) + ((spart ^ swz(row)) << 4);
+    unsigned off = kOobOff;
+    if ((wave + 4 * i) * 16 < npix_in) {   // wave-uniform
+      const int row = (wave + 4 * i) * 16 + srow;
+      const int tmp = fdiv20(row, p.mIW);
+      const int ix = row - (int)__umul24(tmp, IW);
+      const int g = fdiv20(tmp, p.mIH);
+      const int iy = tmp - (int)__umul24(g, IH);
+      const int n = n0 + g, gy = gy0 + iy, gx = gx0 + ix;
+      const bool ok = row < npix_in && n < p.N && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win;
+      const unsigned pix = __umul24(__umul24(n, p.Hin) + gy, p.Win) + gx;
+      off = ok ? pix * cinb + ((spart ^ swz(row)) << 4) : kOobOff;
     }
     src_off[i] = off;
   }
-
+  // weights: LDS row (tap, nb*16 + r) holds cout 4*NB*(r>>2) + 4*nb + (r&3) of this block
   auto stage = [&](int c, unsigned char* sb) {
-    const int coff = c * CK * (int)sizeof(T);
+    const unsigned coff = (unsigned)c * (CK * ESZ);
 #pragma unroll
     for (int i = 0; i < MAXG; ++i) {
       const int gidx = wave + 4 * i;
-      if (gidx < in_groups) {
-        const int row = gidx * 16 + srow;
-        const char* src = src_off[i] >= 0 ? in_base + (unsigned)(src_off[i] + coff) : zero + ((spart ^ swz(row)) << 4);
-        glds16(src, sb + gidx * (16 * ROWB));
-      }
+      if (gidx < in_groups) blds16(r_in, src_off[i] + coff, sb + gidx * (16 * ROWB));
     }
-    // weights: LDS row (tap, nb*16 + r) holds cout 4*NB*(r>>2) + 4*nb + (r&3) of this block
     for (int gidx = wave; gidx < WGROUPS; gidx += 4) {
       const int wr = gidx * 16 + srow;
-      const int tap = wr / BN;
-      const int rho = wr - tap * BN;
+      const int tap = wr / BN;   // BN is a power of two
+      const int rho = wr & (BN - 1);
       const int co = (4 * NB) * ((rho & 15) >> 2) + 4 * (rho >> 4) + (rho & 3);
-      const long e = ((long)(tap * p.CoutPad + cb * BN + co) * p.Cin) * (long)sizeof(T) + coff;
-      glds16(w_base + e + ((spart ^ swz(wr)) << 4), sb + in_bytes + gidx * (16 * ROWB));
+      const unsigned e = __umul24(__umul24(tap, p.CoutPad) + cb * BN + co, cinb) + coff;
+      blds16(r_w, e + ((spart ^ swz(wr)) << 4), sb + in_bytes + gidx * (16 * ROWB));
     }
   };
 
-  int prow[4];
+  // ---- the lane's MBW output pixels
+  int prow[MBW];        // LDS row of the pixel's (0,0) tap
+  unsigned ooff[MBW];   // byte offset of its 4*NB-channel vector in the NHWC output (kOobOff = masked)
+  int ocrd[MBW];        // y | x << 10 | n << 20 (for the up-sampled addends / the NCHW form)
+  const int cbase = cb * BN + 4 * NB * kg;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int m = (wave + 4 * i) * 16 + li;
-    m = m < M ? m : M - 1;
-    const int g = fdiv(m, p.mRT);
-    const int rem = m - g * RT;
-    const int r = fdiv(rem, p.mTW);
-    const int x = rem - r * p.TW;
-    prow[i] = (g * IH + r * STRIDE) * IW + x * STRIDE;
+  for (int i = 0; i < MBW; ++i) {
+    const int m0 = (wave + 4 * i) * 16 + li;
+    const int m = m0 < M ? m0 : M - 1;
+    const int g = fdiv20(m, p.mRT);
+    const int rem = m - (int)__umul24(g, RT);
+    const int r = fdiv20(rem, p.mTW);
+    const int x = rem - (int)__umul24(r, p.TW);
+    prow[i] = (int)__umul24(__umul24(g, IH) + r * STRIDE, IW) + x * STRIDE;
+    const int n = n0 + g, y = y0 + r, xo = x0 + x;
+    const bool ok = m0 < M && n < p.N && y < p.Hout && xo < p.Wout && (NCHW || cbase < p.Cout);
+    const unsigned pix = __umul24(__umul24(n, p.Hout) + y, p.Wout) + xo;
+    ooff[i] = ok ? (pix * p.Cout + cbase) * (unsigned)ESZ : kOobOff;
+    ocrd[i] = ok ? (y | (xo << 10) | (n << 20)) : -1;
   }
   const int wswz = swz(li);  // weight rows: (tap*BN + nb*16) is a multiple of 16 -> swizzle depends on li only
 
-  f32x4 acc[4][NB];
+  f32x4 acc[MBW][NB];
+  {
+    f32x4 bias[NB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int nb = 0; nb < NB; ++nb) bias[nb] = *reinterpret_cast<const f32x4*>(p.bias + cbase + 4 * nb);
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) acc[i][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MBW; ++i)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[i][nb] = bias[nb];
+  }
 
   stage(0, smem);
   for (int c = 0; c < nchunks; ++c) {
@@ -245,15 +304,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
           for (int nb = 0; nb < NB; ++nb)
             wf[nb] = *reinterpret_cast<const f32x2*>(wb + (tap * BN + nb * 16) * ROWB + ((part ^ wswz) << 4) + sub);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            if (wave + 4 * i < nmb) {
-              const int row = prow[i] + tap_rows;
-              const f32x2 pf = *reinterpret_cast<const f32x2*>(sb + row * ROWB + ((part ^ swz(row)) << 4) + sub);
+          for (int i = 0; i < MBW; ++i) {
+            const int row = prow[i] + tap_rows;
+            const f32x2 pf = *reinterpret_cast<const f32x2*>(sb + row * ROWB + ((part ^ swz(row)) << 4) + sub);
 #pragma unroll
-              for (int nb = 0; nb < NB; ++nb) {
-                acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nb][0], pf[0], acc[i][nb], 0, 0, 0);
-                acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nb][1], pf[1], acc[i][nb], 0, 0, 0);
-              }
+            for (int nb = 0; nb < NB; ++nb) {
+              acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nb][0], pf[0], acc[i][nb], 0, 0, 0);
+              acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nb][1], pf[1], acc[i][nb], 0, 0, 0);
             }
           }
         }
@@ -263,71 +320,60 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
         for (int nb = 0; nb < NB; ++nb)
           wf[nb] = *reinterpret_cast<const bf16x8*>(wb + (tap * BN + nb * 16) * ROWB + ((kg ^ wswz) << 4));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (wave + 4 * i < nmb) {
-            const int row = prow[i] + tap_rows;
-            const bf16x8 pf = *reinterpret_cast<const bf16x8*>(sb + row * ROWB + ((kg ^ swz(row)) << 4));
+        for (int i = 0; i < MBW; ++i) {
+          const int row = prow[i] + tap_rows;
+          const bf16x8 pf = *reinterpret_cast<const bf16x8*>(sb + row * ROWB + ((kg ^ swz(row)) << 4));
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb)
-              acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb], pf, acc[i][nb], 0, 0, 0);
-          }
+          for (int nb = 0; nb < NB; ++nb)
+            acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb], pf, acc[i][nb], 0, 0, 0);
         }
       }
     }
   }
 
-  // ---- epilogue: lane holds couts cbase .. cbase + 4*NB - 1 of pixel m (acc[i][nb][q] = cbase + 4*nb + q)
-  const int cbase = cb * BN + 4 * NB * kg;
-  f32x4 bias[NB];
+  // ---- epilogue (acc = conv + bias): lane holds couts cbase .. cbase + 4*NB - 1 of pixel i
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) bias[nb] = *reinterpret_cast<const f32x4*>(p.bias + cbase + 4 * nb);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = (wave + 4 * i) * 16 + li;
-    if (m >= M) continue;
-    const int g = fdiv(m, p.mRT);
-    const int rem = m - g * RT;
-    const int r = fdiv(rem, p.mTW);
-    const int xo = x0 + rem - r * p.TW;
-    const int n = n0 + g;
-    const int y = y0 + r;
-    if (n >= p.N || y >= p.Hout || xo >= p.Wout) continue;
-    const size_t pix = ((size_t)(n * p.Hout + y) * p.Wout + xo);
+  for (int i = 0; i < MBW; ++i) {
     f32x4 v[NB];
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) v[nb] = acc[i][nb] + bias[nb];
-    if (p.out_nchw_f32) {
-      float* o = reinterpret_cast<float*>(p.out);
+    for (int nb = 0; nb < NB; ++nb) v[nb] = acc[i][nb];
+    if constexpr (NCHW) {
+      const int crd = ocrd[i];
+      const int y = crd & 1023, xo = (crd >> 10) & 1023, n = crd >> 20;
+      const unsigned hw = __umul24(p.Hout, p.Wout);
+      const unsigned base = __umul24(__umul24(__umul24(n, p.Cout), p.Hout) + y, p.Wout) + xo;
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int c = cbase + 4 * nb + q;
-          if (c < p.Cout) {
-            float f = v[nb][q];
-            if (p.relu) f = f > 0.f ? f : 0.f;
-            o[((size_t)(n * p.Cout + c) * p.Hout + y) * p.Wout + xo] = f;
+          const int cc = cbase + 4 * nb + q;
+          float f = v[nb][q];
+          if (p.relu) f = f > 0.f ? f : 0.f;
+          const unsigned off = (crd >= 0 && cc < p.Cout) ? (base + cc * hw) * 4u : kOobOff;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, f), r_out, off, 0, 0);
+        }
+    } else {
+      if (p.res) add_vec_buf<T, NB>(v, r_res, ooff[i]);
+      if (p.nup) {   // wave-uniform, rare (exchange-unit outputs only)
+        const int crd = ocrd[i];
+        const int y = crd & 1023, xo = (crd >> 10) & 1023, n = crd >> 20;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          if (u < p.nup) {
+            const int s = p.up_shift[u];
+            const long up_pix = ((long)(n * (p.Hout >> s) + (y >> s)) * (p.Wout >> s) + (xo >> s));
+            if (crd >= 0) add_vec<T, NB>(v, reinterpret_cast<const T*>(p.up[u]) + up_pix * p.Cout + cbase);
           }
         }
-      continue;
-    }
-    if (cbase >= p.Cout) continue;   // NHWC: Cout is a multiple of 16 = 4*NB*k, whole vectors only
-    if (p.res) add_vec<T, NB>(v, reinterpret_cast<const T*>(p.res) + pix * p.Cout + cbase);
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      if (u < p.nup) {
-        const int s = p.up_shift[u];
-        const size_t up_pix = ((size_t)(n * (p.Hout >> s) + (y >> s)) * (p.Wout >> s) + (xo >> s));
-        add_vec<T, NB>(v, reinterpret_cast<const T*>(p.up[u]) + up_pix * p.Cout + cbase);
       }
-    }
-    if (p.relu) {
+      if (p.relu) {
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[nb][q] = v[nb][q] > 0.f ? v[nb][q] : 0.f;
+          for (int q = 0; q < 4; ++q) v[nb][q] = v[nb][q] > 0.f ? v[nb][q] : 0.f;
+      }
+      store_vec_buf<T, NB>(r_out, ooff[i], v);
     }
-    store_vec<T, NB>(reinterpret_cast<T*>(p.out) + pix * p.Cout + cbase, v);
   }
 }
 
@@ -469,7 +515,7 @@ size_t conv_choose_tile(ConvParams& p, int ks, int stride, int dtype, int* nb_ou
   p.IW = (TW - 1) * stride + ks;
   p.tiles_x = ceil_div(p.Wout, TW);
   p.tiles_y = ceil_div(p.Hout, R);
-  auto magic = [](int d) { return (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); };
+  auto magic = [](int d) { return (unsigned)(((1u << 20) + (unsigned)d - 1) / (unsigned)d); };   // fdiv20
   p.mIW = magic(p.IW);
   p.mIH = magic(p.IH);
   p.mRT = magic(R * TW);
@@ -478,10 +524,10 @@ size_t conv_choose_tile(ConvParams& p, int ks, int stride, int dtype, int* nb_ou
   return lds(G, R, NB);
 }
 
-template <typename T, int KS, int STRIDE, int NB>
+template <typename T, int KS, int STRIDE, int NB, int MBW, bool NCHW>
 static int describe_one(const ConvParams& p, size_t lds, Launch* out) {
   static bool attr_set = false;
-  const void* kern = reinterpret_cast<const void*>(&conv_mfma_kernel<T, KS, STRIDE, NB>);
+  const void* kern = reinterpret_cast<const void*>(&conv_mfma_kernel<T, KS, STRIDE, NB, MBW, NCHW>);
   if (!attr_set) {
     UDP_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
@@ -494,14 +540,30 @@ static int describe_one(const ConvParams& p, size_t lds, Launch* out) {
   return UDP_OK;
 }
 
+template <typename T, int KS, int STRIDE, int NB, bool NCHW>
+static int describe_mbw(const ConvParams& p, int mbw, size_t lds, Launch* out) {
+  switch (mbw) {
+    case 1: return describe_one<T, KS, STRIDE, NB, 1, NCHW>(p, lds, out);
+    case 2: return describe_one<T, KS, STRIDE, NB, 2, NCHW>(p, lds, out);
+    case 3: return describe_one<T, KS, STRIDE, NB, 3, NCHW>(p, lds, out);
+    case 4: return describe_one<T, KS, STRIDE, NB, 4, NCHW>(p, lds, out);
+  }
+  return fail(UDP_ERR_UNSUPPORTED, "conv tile of %d pixel blocks per wave has no kernel", mbw);
+}
+
 template <typename T>
-static int describe_conv_t(const ConvParams& p, int ks, int stride, int nb, size_t lds, Launch* out) {
-#define UDP_CASE(K, S, B) \
-  if (ks == K && stride == S && nb == B) return describe_one<T, K, S, B>(p, lds, out);
+static int describe_conv_t(const ConvParams& p, int ks, int stride, int nb, int mbw, size_t lds, Launch* out) {
+#define UDP_CASE(K, S, B)                                                              \
+  if (ks == K && stride == S && nb == B && !p.out_nchw_f32) return describe_mbw<T, K, S, B, false>(p, mbw, lds, out);
+#define UDP_CASE_OUT(K, S, B)                                                          \
+  if (ks == K && stride == S && nb == B && p.out_nchw_f32) return describe_mbw<T, K, S, B, true>(p, mbw, lds, out);
   UDP_CASE(3, 1, 2) UDP_CASE(3, 1, 4) UDP_CASE(3, 2, 2) UDP_CASE(3, 2, 4)
   UDP_CASE(1, 1, 2) UDP_CASE(1, 1, 4)
+  UDP_CASE_OUT(1, 1, 2) UDP_CASE_OUT(1, 1, 4) UDP_CASE_OUT(3, 1, 2) UDP_CASE_OUT(3, 1, 4)
 #undef UDP_CASE
-  return fail(UDP_ERR_UNSUPPORTED, "conv ks=%d stride=%d nb=%d has no kernel", ks, stride, nb);
+#undef UDP_CASE_OUT
+  return fail(UDP_ERR_UNSUPPORTED, "conv ks=%d stride=%d nb=%d nchw_out=%d has no kernel", ks, stride, nb,
+              p.out_nchw_f32);
 }
 
 // Fills `out` with the kernel, grid and arguments of one fused conv (tile choice included).
@@ -510,14 +572,16 @@ int describe_conv(ConvParams p, int dtype, int ks, int stride, Launch* out) {
   if (!p.out_nchw_f32 && p.Cout % 16 != 0)
     return fail(UDP_ERR_UNSUPPORTED, "NHWC conv Cout=%d is not a multiple of 16", p.Cout);
   const size_t esz = dtype == UDP_F32 ? 4 : 2;
-  if ((size_t)p.N * p.Hin * p.Win * p.Cin * esz >= 0x7FFF0000u)
-    return fail(UDP_ERR_UNSUPPORTED, "conv input exceeds the 2 GiB the 32-bit staging offsets cover; split the batch");
+  if ((size_t)p.N * p.Hin * p.Win * p.Cin * esz >= 0x7FFF0000u || (size_t)p.N * p.Hout * p.Wout * p.Cout * 4 >= 0x7FFF0000u ||
+      p.N >= 2048)
+    return fail(UDP_ERR_UNSUPPORTED, "conv tensor exceeds the 2 GiB the 32-bit buffer offsets cover; split the batch");
   int nb = 2;
   const size_t lds = conv_choose_tile(p, ks, stride, dtype, &nb);
   if (p.CoutPad % (nb * 16) != 0)
     return fail(UDP_ERR_UNSUPPORTED, "conv CoutPad=%d is not a multiple of %d", p.CoutPad, nb * 16);
-  if (dtype == UDP_F32) return describe_conv_t<float>(p, ks, stride, nb, lds, out);
-  return describe_conv_t<__bf16>(p, ks, stride, nb, lds, out);
+  const int mbw = ceil_div(ceil_div(p.G * p.R * p.TW, 16), 4);
+  if (dtype == UDP_F32) return describe_conv_t<float>(p, ks, stride, nb, mbw, lds, out);
+  return describe_conv_t<__bf16>(p, ks, stride, nb, mbw, lds, out);
 }
 
 int describe_stem(const ConvParams& p, int dtype, Launch* out) {
