@@ -47,6 +47,7 @@ struct ConvParams {
   int G, R, TW;          // tile = G images x R rows x TW cols of output
   int IH, IW;            // input halo tile per image
   int tiles_x, tiles_y;  // tiles per image group
+  unsigned mTX, mTY;     // ceil(2^32/d), 0 for d == 1 (tile index decode, t < 65536)
   int ntiles;            // all tiles of the launch (persistent workgroups stride over them)
   unsigned mIW, mIH, mRT, mTW;  // ceil(2^20/d): x/d == (x*m) >> 20 for x*d < 2^20 (24-bit multiply)
   int relu;

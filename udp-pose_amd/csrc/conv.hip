@@ -40,6 +40,23 @@ constexpr int MAXG = 10;   // 16-row staging groups per wave for the input tile 
 // 16-byte part p of LDS row r is stored at part position p ^ swz(r)
 __device__ __forceinline__ int swz(int row) { return (-(row >> 2)) & 3; }
 
+#ifdef UDP_STAMPS
+// Diagnostic build (libudp_pose_hip_stamps.so, tools/stamp_conv.py): s_memtime stamps per wave into a
+// buffer nothing else reads.  Never compiled into the product library.
+__device__ unsigned long long* g_stamps;
+__device__ __forceinline__ void stamp(int k) {
+  __builtin_amdgcn_sched_barrier(0);
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  if ((threadIdx.x & 63) == 0 && g_stamps)
+    g_stamps[((size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 4 + (threadIdx.x >> 6)) * 8 + k] = t;
+}
+#define UDP_STAMP(k) stamp(k)
+#else
+#define UDP_STAMP(k)
+#endif
+
 template <typename T>
 struct Tr;
 template <>
@@ -175,6 +192,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
   constexpr int WGROUPS = TAPS * BN / 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
+  UDP_STAMP(0);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -282,12 +300,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
       for (int nb = 0; nb < NB; ++nb) acc[i][nb] = bias[nb];
   }
 
+  UDP_STAMP(1);
   stage(0, smem);
+  UDP_STAMP(2);
   for (int c = 0; c < nchunks; ++c) {
     // chunk c has landed (explicit wait: the compiler is not obliged to track LDS-DMA) and every
     // wave is done with chunk c-1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (c == 0) UDP_STAMP(3);
     __syncthreads();
+    if (c == 0) UDP_STAMP(4);
     if (c + 1 < nchunks) stage(c + 1, smem + ((c + 1) & 1) * stage_bytes);
     const unsigned char* sb = smem + (c & 1) * stage_bytes;
     const unsigned char* wb = sb + in_bytes + li * ROWB;
@@ -331,6 +353,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     }
   }
 
+  UDP_STAMP(5);
   // ---- epilogue (acc = conv + bias): lane holds couts cbase .. cbase + 4*NB - 1 of pixel i
 #pragma unroll
   for (int i = 0; i < MBW; ++i) {
@@ -374,6 +397,227 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
       }
       store_vec_buf<T, NB>(r_out, ooff[i], v);
     }
+  }
+  UDP_STAMP(6);
+#ifdef UDP_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  UDP_STAMP(7);
+#endif
+}
+
+// Persistent form of conv_mfma_kernel for layers whose Cin fits ONE 64-byte chunk (bf16 Cin = 32:
+// the high-resolution branch, the most HBM-heavy and most numerous launches).  A workgroup keeps
+// the whole weight block in LDS, walks tiles t = blockIdx.x, += gridDim.x and streams tile t+1's halo
+// into the second input buffer while tile t feeds the MFMAs and its epilogue runs: the per-tile fixed
+// cost (weight DMA, prologue index math, DMA latency) is paid once or hidden.  NHWC output only.
+constexpr int MAXGP = 6;   // 16-row staging groups per wave (input tile <= 384 rows)
+
+__device__ __forceinline__ int udiv16(int x, unsigned m) { return m ? (int)__umulhi((unsigned)x, m) : x; }   // x < 65536
+
+template <typename T, int KS, int STRIDE, int NB, int MBW>
+__global__ __launch_bounds__(256) void conv_mfma_persist1(const ConvParams p) {
+  constexpr int ESZ = (int)sizeof(T);
+  constexpr int BN = NB * 16;
+  constexpr int PAD = KS / 2;
+  constexpr int TAPS = KS * KS;
+  constexpr int WGROUPS = TAPS * BN / 16;
+  constexpr int WBYTES = TAPS * BN * ROWB;
+  constexpr int NSTORE = MBW * (std::is_same<T, float>::value ? NB : NB / 2);   // store instructions per tile and wave
+  static_assert(!std::is_same<T, float>::value || true, "");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15;
+  const int kg = lane >> 4;
+  const int cb = blockIdx.y;
+
+  const int IH = p.IH, IW = p.IW;
+  const int npix_in = p.G * IH * IW;
+  const int in_groups = (npix_in + 15) >> 4;
+  const int in_bytes = in_groups * 16 * ROWB;
+  const int RT = p.R * p.TW;
+  const int M = p.G * RT;
+  const unsigned cinb = (unsigned)p.Cin * ESZ;
+  unsigned char* const w_lds = smem;
+  unsigned char* const in_lds = smem + WBYTES;
+
+  const unsigned out_pix = (unsigned)p.N * p.Hout * p.Wout;
+  const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.in), 0, (unsigned)p.N * p.Hin * p.Win * cinb, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.wgt), 0, (unsigned)TAPS * p.CoutPad * cinb, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, out_pix * p.Cout * ESZ, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.res), 0, p.res ? out_pix * p.Cout * ESZ : 0, 0x00020000);
+
+  // ---- tile-invariant per-lane state
+  const int srow = lane >> 2;
+  const int spart = lane & 3;
+  int s_rel[MAXGP];   // byte offset relative to the tile's input origin (swizzled part included)
+  int s_crd[MAXGP];   // iy | ix << 10 | g << 20, -1 = row outside the tile
+#pragma unroll
+  for (int i = 0; i < MAXGP; ++i) {
+    s_rel[i] = 0;
+    s_crd[i] = -1;
+    if ((wave + 4 * i) * 16 < npix_in) {
+      const int row = (wave + 4 * i) * 16 + srow;
+      const int tmp = fdiv20(row, p.mIW);
+      const int ix = row - (int)__umul24(tmp, IW);
+      const int g = fdiv20(tmp, p.mIH);
+      const int iy = tmp - (int)__umul24(g, IH);
+      s_rel[i] = (int)((__umul24(__umul24(g, p.Hin) + iy, p.Win) + ix) * cinb) + ((spart ^ swz(row)) << 4);
+      s_crd[i] = row < npix_in ? (iy | (ix << 10) | (g << 20)) : -1;
+    }
+  }
+  const int cbase = cb * BN + 4 * NB * kg;
+  int prow[MBW];    // LDS row of the pixel's (0,0) tap
+  int o_rel[MBW];   // byte offset of the lane's channel vector relative to the tile's output origin
+  int o_crd[MBW];   // r | x << 10 | g << 20, -1 = no pixel
+#pragma unroll
+  for (int i = 0; i < MBW; ++i) {
+    const int m0 = (wave + 4 * i) * 16 + li;
+    const int m = m0 < M ? m0 : M - 1;
+    const int g = fdiv20(m, p.mRT);
+    const int rem = m - (int)__umul24(g, RT);
+    const int r = fdiv20(rem, p.mTW);
+    const int x = rem - (int)__umul24(r, p.TW);
+    prow[i] = (int)__umul24(__umul24(g, IH) + r * STRIDE, IW) + x * STRIDE;
+    o_rel[i] = (int)(((__umul24(__umul24(g, p.Hout) + r, p.Wout) + x) * p.Cout + cbase) * ESZ);
+    o_crd[i] = (m0 < M && cbase < p.Cout) ? (r | (x << 10) | (g << 20)) : -1;
+  }
+  const int wswz = swz(li);
+  f32x4 bias[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) bias[nb] = *reinterpret_cast<const f32x4*>(p.bias + cbase + 4 * nb);
+
+  auto tile_origin = [&](int t, int& n0, int& y0, int& x0) {
+    const int q1 = udiv16(t, p.mTX);
+    const int tx = t - q1 * p.tiles_x;
+    const int q2 = udiv16(q1, p.mTY);
+    n0 = q2 * p.G;
+    y0 = (q1 - q2 * p.tiles_y) * p.R;
+    x0 = tx * p.TW;
+  };
+  auto stage_in = [&](int t, unsigned char* sb) {
+    int n0, y0, x0;
+    tile_origin(t, n0, y0, x0);
+    const int gy0 = y0 * STRIDE - PAD, gx0 = x0 * STRIDE - PAD;
+    const int org = ((n0 * p.Hin + gy0) * p.Win + gx0) * (int)cinb;
+#pragma unroll
+    for (int i = 0; i < MAXGP; ++i) {
+      const int gidx = wave + 4 * i;
+      if (gidx < in_groups) {
+        const int crd = s_crd[i];
+        const int gy = gy0 + (crd & 1023), gx = gx0 + ((crd >> 10) & 1023), n = n0 + ((crd >> 20) & 1023);
+        const bool ok = crd >= 0 && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win && n < p.N;
+        blds16(r_in, ok ? (unsigned)(org + s_rel[i]) : kOobOff, sb + gidx * (16 * ROWB));
+      }
+    }
+  };
+
+  const int ntiles = p.ntiles;
+  int t = blockIdx.x;
+  if (t >= ntiles) return;
+  // weights once: LDS row (tap, nb*16 + r) holds cout 4*NB*(r>>2) + 4*nb + (r&3) of this block
+  for (int gidx = wave; gidx < WGROUPS; gidx += 4) {
+    const int wr = gidx * 16 + srow;
+    const int tap = wr / BN;
+    const int rho = wr & (BN - 1);
+    const int co = (4 * NB) * ((rho & 15) >> 2) + 4 * (rho >> 4) + (rho & 3);
+    const unsigned e = __umul24(__umul24(tap, p.CoutPad) + cb * BN + co, cinb);
+    blds16(r_w, e + ((spart ^ swz(wr)) << 4), w_lds + gidx * (16 * ROWB));
+  }
+  stage_in(t, in_lds);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  const unsigned char* wb = w_lds + li * ROWB + (std::is_same<T, float>::value ? 0 : ((kg ^ wswz) << 4));
+  for (int it = 0; t < ntiles; t += gridDim.x, ++it) {
+    // every wave has waited for its own DMA of this tile; after the barrier all of it is visible and
+    // nobody still reads the other buffer
+    __builtin_amdgcn_s_barrier();
+    if (t + (int)gridDim.x < ntiles) stage_in(t + gridDim.x, in_lds + ((it + 1) & 1) * in_bytes);
+    const unsigned char* sb = in_lds + (it & 1) * in_bytes;
+
+    f32x4 acc[MBW][NB];
+#pragma unroll
+    for (int i = 0; i < MBW; ++i)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[i][nb] = bias[nb];
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int ky = tap / KS, kx = tap % KS;
+      const int tap_rows = ky * IW + kx;
+      if constexpr (std::is_same<T, float>::value) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int part = 2 * ks + (kg >> 1), sub = (kg & 1) * 8;
+          f32x2 wf[NB];
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            wf[nb] = *reinterpret_cast<const f32x2*>(wb + (tap * BN + nb * 16) * ROWB + ((part ^ wswz) << 4) + sub);
+#pragma unroll
+          for (int i = 0; i < MBW; ++i) {
+            const int row = prow[i] + tap_rows;
+            const f32x2 pf = *reinterpret_cast<const f32x2*>(sb + row * ROWB + ((part ^ swz(row)) << 4) + sub);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+              acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nb][0], pf[0], acc[i][nb], 0, 0, 0);
+              acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nb][1], pf[1], acc[i][nb], 0, 0, 0);
+            }
+          }
+        }
+      } else {
+        bf16x8 wf[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) wf[nb] = *reinterpret_cast<const bf16x8*>(wb + (tap * BN + nb * 16) * ROWB);
+#pragma unroll
+        for (int i = 0; i < MBW; ++i) {
+          const int row = prow[i] + tap_rows;
+          const bf16x8 pf = *reinterpret_cast<const bf16x8*>(sb + row * ROWB + ((kg ^ swz(row)) << 4));
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb], pf, acc[i][nb], 0, 0, 0);
+        }
+      }
+    }
+
+    // ---- epilogue of tile t
+    int n0, y0, x0;
+    tile_origin(t, n0, y0, x0);
+    const int o_org = ((n0 * p.Hout + y0) * p.Wout + x0) * p.Cout * ESZ;
+#pragma unroll
+    for (int i = 0; i < MBW; ++i) {
+      const int crd = o_crd[i];
+      const int y = y0 + (crd & 1023), xo = x0 + ((crd >> 10) & 1023), n = n0 + ((crd >> 20) & 1023);
+      const bool ok = crd >= 0 && y < p.Hout && xo < p.Wout && n < p.N;
+      const unsigned voff = ok ? (unsigned)(o_org + o_rel[i]) : kOobOff;
+      f32x4 v[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) v[nb] = acc[i][nb];
+      if (p.res) add_vec_buf<T, NB>(v, r_res, voff);
+      if (p.nup) {   // wave-uniform, rare
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          if (u < p.nup) {
+            const int s = p.up_shift[u];
+            const long up_pix = ((long)(n * (p.Hout >> s) + (y >> s)) * (p.Wout >> s) + (xo >> s));
+            if (ok) add_vec<T, NB>(v, reinterpret_cast<const T*>(p.up[u]) + up_pix * p.Cout + cbase);
+          }
+        }
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[nb][q] = v[nb][q] > 0.f ? v[nb][q] : 0.f;
+      }
+      store_vec_buf<T, NB>(r_out, voff, v);
+    }
+    // the next tile's DMA was issued before this tile's NSTORE stores: it has landed once at most
+    // NSTORE memory operations are still outstanding (they complete in issue order)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
   }
 }
 
@@ -520,6 +764,10 @@ size_t conv_choose_tile(ConvParams& p, int ks, int stride, int dtype, int* nb_ou
   p.mIH = magic(p.IH);
   p.mRT = magic(R * TW);
   p.mTW = magic(TW);
+  p.ntiles = ceil_div(p.N, G) * p.tiles_y * p.tiles_x;
+  auto magic32 = [](int d) { return d == 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); };
+  p.mTX = magic32(p.tiles_x);
+  p.mTY = magic32(p.tiles_y);
   *nb_out = NB;
   return lds(G, R, NB);
 }
@@ -566,6 +814,53 @@ static int describe_conv_t(const ConvParams& p, int ks, int stride, int nb, int 
               p.out_nchw_f32);
 }
 
+template <int KS, int STRIDE, int NB, int MBW>
+static int describe_persist_one(const ConvParams& p, size_t lds, int grid_x, Launch* out) {
+  static bool attr_set = false;
+  const void* kern = reinterpret_cast<const void*>(&conv_mfma_persist1<__bf16, KS, STRIDE, NB, MBW>);
+  if (!attr_set) {
+    UDP_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  out->fn = kern;
+  out->grid = dim3(grid_x, p.CoutPad / (NB * 16));
+  out->block = dim3(256);
+  out->lds = (unsigned)lds;
+  out->p = p;
+  return UDP_OK;
+}
+
+template <int KS, int STRIDE, int NB>
+static int describe_persist_mbw(const ConvParams& p, int mbw, size_t lds, int grid_x, Launch* out) {
+  switch (mbw) {
+    case 1: return describe_persist_one<KS, STRIDE, NB, 1>(p, lds, grid_x, out);
+    case 2: return describe_persist_one<KS, STRIDE, NB, 2>(p, lds, grid_x, out);
+    case 3: return describe_persist_one<KS, STRIDE, NB, 3>(p, lds, grid_x, out);
+    case 4: return describe_persist_one<KS, STRIDE, NB, 4>(p, lds, grid_x, out);
+  }
+  return 1;
+}
+
+// Persistent single-chunk form (bf16, Cin = 32): returns 1 when it does not apply.
+static int describe_persist(const ConvParams& p, int ks, int stride, int nb, int mbw, Launch* out) {
+  const int npix = p.G * p.IH * p.IW;
+  if (p.out_nchw_f32 || p.Cin != 32 || npix > MAXGP * 64 || p.ntiles >= 65536) return 1;
+  const size_t lds = (size_t)(ks * ks * nb * 16 + 2 * ((npix + 15) / 16) * 16) * ROWB;
+  int per_cu = (int)((150 * 1024) / lds);
+  if (per_cu > 4) per_cu = 4;
+  if (per_cu < 1) return 1;
+  const int cblocks = p.CoutPad / (nb * 16);
+  const int budget = ceil_div(256 * per_cu, cblocks);
+  if (p.ntiles < 2 * budget) return 1;               // one tile per workgroup: nothing to overlap
+  const int rounds = ceil_div(p.ntiles, budget);
+  const int grid_x = ceil_div(p.ntiles, rounds);
+#define UDP_CASE(K, S, B) \
+  if (ks == K && stride == S && nb == B) return describe_persist_mbw<K, S, B>(p, mbw, lds, grid_x, out);
+  UDP_CASE(3, 1, 2) UDP_CASE(3, 1, 4) UDP_CASE(3, 2, 2) UDP_CASE(3, 2, 4) UDP_CASE(1, 1, 2) UDP_CASE(1, 1, 4)
+#undef UDP_CASE
+  return 1;
+}
+
 // Fills `out` with the kernel, grid and arguments of one fused conv (tile choice included).
 int describe_conv(ConvParams p, int dtype, int ks, int stride, Launch* out) {
   if (p.Cin % 32 != 0) return fail(UDP_ERR_UNSUPPORTED, "conv Cin=%d is not a multiple of 32", p.Cin);
@@ -580,6 +875,10 @@ int describe_conv(ConvParams p, int dtype, int ks, int stride, Launch* out) {
   if (p.CoutPad % (nb * 16) != 0)
     return fail(UDP_ERR_UNSUPPORTED, "conv CoutPad=%d is not a multiple of %d", p.CoutPad, nb * 16);
   const int mbw = ceil_div(ceil_div(p.G * p.R * p.TW, 16), 4);
+  if (dtype == UDP_BF16 && getenv("UDP_POSE_NO_PERSIST") == nullptr) {
+    const int rc = describe_persist(p, ks, stride, nb, mbw, out);
+    if (rc <= 0) return rc;
+  }
   if (dtype == UDP_F32) return describe_conv_t<float>(p, ks, stride, nb, mbw, lds, out);
   return describe_conv_t<__bf16>(p, ks, stride, nb, mbw, lds, out);
 }
@@ -609,6 +908,13 @@ int describe_fuse(const ConvParams& p, int dtype, Launch* out) {
   out->p = p;
   return UDP_OK;
 }
+
+#ifdef UDP_STAMPS
+extern "C" int udp_debug_set_stamps(unsigned long long* dev_buf) {
+  UDP_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &dev_buf, sizeof(dev_buf)));
+  return UDP_OK;
+}
+#endif
 
 int run_launch(const Launch& l, hipStream_t s) {
   void* args[] = {const_cast<ConvParams*>(&l.p)};
