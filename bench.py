@@ -38,11 +38,16 @@ PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # dense MFMA peaks, MI355X_MICR
 PEAK_HBM_GBS = 8000.0
 
 
-def build_net(dtype, target_type="gaussian"):
-    calib_path = os.path.join(ROOT, "tests", "golden", "bn_calib_w32_%s.npz" % target_type)
+# model -> (MODEL.EXTRA, input H, input W, weight seed); w32 = BASELINE.json configs[1], w48 = configs[3]
+MODELS_CFG = {"w32": (synth.W32_EXTRA, 256, 192, 0), "w48": (synth.scaled_extra(48), 384, 288, 2)}
+
+
+def build_net(dtype, target_type="gaussian", model="w32"):
+    extra, _, _, seed = MODELS_CFG[model]
+    calib_path = os.path.join(ROOT, "tests", "golden", "bn_calib_%s_%s.npz" % (model, target_type))
     calib = dict(np.load(calib_path)) if os.path.exists(calib_path) else None
-    sd = synth.synth_state_dict(synth.W32_EXTRA, 17, target_type, seed=0, bn_calib=calib)
-    cfg = {"MODEL": {"NAME": "pose_hrnet", "EXTRA": synth.W32_EXTRA, "NUM_JOINTS": 17, "TARGET_TYPE": target_type}}
+    sd = synth.synth_state_dict(extra, 17, target_type, seed=seed, bn_calib=calib)
+    cfg = {"MODEL": {"NAME": "pose_hrnet", "EXTRA": extra, "NUM_JOINTS": 17, "TARGET_TYPE": target_type}}
     net = MODELS["pose_hrnet"](cfg, is_train=False, dtype=dtype)
     net.load_state_dict(sd, strict=True)
     return sd, net
@@ -51,13 +56,13 @@ def build_net(dtype, target_type="gaussian"):
 class HotPath:
     """forward(+mirrored) -> flip fuse -> decode, all on device, fixed buffers."""
 
-    def __init__(self, net, batch, device, seed):
-        self.net, self.n = net.to(device), batch
-        crops = synth.synth_crops(min(batch, 8), 256, 192, seed=seed)
+    def __init__(self, net, batch, device, seed, h=256, w=192):
+        self.net, self.n, self.h, self.w = net.to(device), batch, h, w
+        crops = synth.synth_crops(min(batch, 8), h, w, seed=seed)
         reps = (batch + crops.shape[0] - 1) // crops.shape[0]
         x = torch.from_numpy(np.tile(crops, (reps, 1, 1, 1))[:batch]).to(device)
         x += 0.01 * torch.randn(x.shape, device=device, generator=torch.Generator(device).manual_seed(seed))
-        self.xin, _ = self.net.io_buffers(batch, 256, 192, True)
+        self.xin, _ = self.net.io_buffers(batch, h, w, True)
         self.xin.copy_(x)
         c, s = synth.synth_center_scale(batch, seed=seed)
         self.center = torch.from_numpy(c.astype(np.float64)).to(device)
@@ -65,13 +70,13 @@ class HotPath:
         src, sign = channel_map(17, COCO_FLIP_PAIRS, False)
         self.src = torch.from_numpy(src).to(device)
         self.sign = torch.from_numpy(sign).to(device)
-        self.fused = torch.empty(batch, 17, 64, 48, device=device)
+        self.fused = torch.empty(batch, 17, h // 4, w // 4, device=device)
 
     def step(self):
         raw = self.net.raw_forward(self.xin, flip_test=True)
         n = self.n
         _lib.check(_lib.lib().udp_flip_fuse(_lib.ptr(raw), C_ptr(raw, n), _lib.ptr(self.src), _lib.ptr(self.sign),
-                                            n, 17, 64, 48, _lib.ptr(self.fused), _lib.stream_ptr()))
+                                            n, 17, self.h // 4, self.w // 4, _lib.ptr(self.fused), _lib.stream_ptr()))
         return decode_device(self.fused, self.center, self.scale, "gaussian", True, 4.0, True, want_idx=False)
 
 
@@ -107,7 +112,7 @@ def roofline(net, hp, steps, dtype):
                  "gbs": round(v[2] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else 0} for k, v in classes.items()}
     traffic = None      # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/pmc_by_op.py)
     tfile = os.path.join(ROOT, "profiles", "r01b_traffic_%s.json" % dtype)
-    if os.path.exists(tfile) and hp.n == 64:
+    if os.path.exists(tfile) and hp.n == 64 and hp.h == 256:
         with open(tfile) as f:
             tc = json.load(f)["classes"].get(dom)
         if tc:
@@ -167,7 +172,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="crops per GPU per step")
+    ap.add_argument("--batch", type=int, default=0, help="crops per GPU per step (default 64; 32 for w48)")
+    ap.add_argument("--model", default="w32", choices=sorted(MODELS_CFG), help="w32 256x192 (headline) or w48 384x288")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches on lane streams instead of hipGraph replay")
@@ -188,9 +194,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)
 
-    sd, net = build_net(args.dtype)
+    extra, in_h, in_w, _ = MODELS_CFG[args.model]
+    if args.batch <= 0:
+        args.batch = 64 if args.model == "w32" else 32
+    sd, net = build_net(args.dtype, model=args.model)
     net.use_graph = not args.no_graph
-    hp = HotPath(net, args.batch, device, seed=100 + rank)
+    hp = HotPath(net, args.batch, device, seed=100 + rank, h=in_h, w=in_w)
 
     def barrier():
         if dist is not None:
@@ -213,24 +222,27 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * args.batch * args.steps / dt
 
-    line = {"metric": "images/sec HRNet-W32 256x192 (infer+decode)", "value": round(value, 1), "unit": "images/s",
+    metric = "images/sec HRNet-W32 256x192 (infer+decode)" if args.model == "w32" else \
+        "images/sec HRNet-W48 384x288 (infer+decode)"
+    line = {"metric": metric, "value": round(value, 1), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": "pose_hrnet_w32 256x192 %s inference, batch=%d per GPU, flip-test on, DARK decode "
-                                   "(forward on 2N images + flip fuse + udp_decode_gaussian)" % (args.dtype, args.batch),
+            "config": {"workload": "pose_hrnet_%s %dx%d %s inference, batch=%d per GPU, flip-test on, DARK decode "
+                                   "(forward on 2N images + flip fuse + udp_decode_gaussian)" %
+                                   (args.model, in_h, in_w, args.dtype, args.batch),
                        "global_batch": world * args.batch, "parallelism": "replicas x%d (no data-path collective)" % world,
-                       "weights": "seeded synthetic, BN stats calibrated (tests/golden/bn_calib_w32_gaussian.npz)"}}
+                       "weights": "seeded synthetic, BN stats calibrated (tests/golden/bn_calib_%s_gaussian.npz)" % args.model}}
     if rank == 0:
         rl = roofline(net, hp, max(1, min(args.steps, 5)), args.dtype)
-        flops_per_img = 2 * 2 * net.program(256, 192).macs_per_image()
+        flops_per_img = 2 * 2 * net.program(in_h, in_w).macs_per_image()
         line["roofline"] = rl
         line["whole_step"] = {"tflops": round(flops_per_img * args.batch / (ms_per_step * 1e-3) / 1e12, 2),
-                              "algorithmic_act_gbs": round(2 * net.program(256, 192).activation_elems_per_image() *
+                              "algorithmic_act_gbs": round(2 * net.program(in_h, in_w).activation_elems_per_image() *
                                                            (2 if args.dtype == "bf16" else 4) * args.batch /
                                                            (ms_per_step * 1e-3) / 1e9, 1),
                               "hbm_peak_gbs": PEAK_HBM_GBS}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.model == "w32":
             cb, x, c, s, ref, ref_hm = cpu_baseline(sd)
             line["cpu_baseline"] = cb
             line["parity_vs_cpu_oracle"] = parity(args.dtype, sd, x, c, s, ref, ref_hm, device)

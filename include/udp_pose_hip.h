@@ -72,7 +72,7 @@ typedef struct udp_conv_op {
   int32_t kind;            /* enum udp_op_kind */
   int32_t ks, stride;      /* kernel size 1|3 (pad = ks/2), stride 1|2 */
   int32_t relu;            /* apply ReLU in the epilogue */
-  int32_t cin, cout;       /* real channel counts (cin multiple of 32 for UDP_OP_CONV) */
+  int32_t cin, cout;       /* real channel counts (cin multiple of 16 for UDP_OP_CONV) */
   int32_t cout_pad;        /* cout rounded up to a multiple of 32: rows of `weights`/`bias` */
   int32_t hin, win, hout, wout;
   int32_t in_buf, out_buf, res_buf; /* activation buffer ids; UDP_BUF_NONE / UDP_BUF_OUTPUT */

@@ -162,6 +162,27 @@ def gen_hrnet(pose_hrnet):
         print("w32", tt, y.shape, "absmax", float(np.abs(y).max()), "std", float(y.std()))
 
 
+def gen_hrnet_w48(pose_hrnet):
+    """Config 4: pose_hrnet_w48 384x288 (widths 48/96/192/384), one crop."""
+    extra = synth.scaled_extra(48)
+    sd = synth.synth_state_dict(extra, 17, "gaussian", seed=2)
+    xc = torch.from_numpy(synth.synth_crops(2, 384, 288, seed=13))
+    yc = o_hrnet.hrnet_forward(sd, extra, xc, calibrate=True)
+    calib = {k: v.numpy().astype(np.float16 if "running_var" not in k else np.float32)
+             for k, v in sd.items() if "running_" in k}
+    calib = {k: v.astype(np.float32) for k, v in calib.items()}      # fp16-rounded means: smaller fixture
+    calib["final_layer.scale"] = np.float32(0.25 / float(yc.std()))
+    np.savez_compressed(os.path.join(OUT, "bn_calib_w48_gaussian.npz"),
+                        **{k: (v.astype(np.float16) if "running_mean" in k else v) for k, v in calib.items()})
+    sd = synth.synth_state_dict(extra, 17, "gaussian", seed=2, bn_calib=calib)
+    net = ref_hrnet(pose_hrnet, extra, 17, "gaussian", sd)
+    x = torch.from_numpy(synth.synth_crops(1, 384, 288, seed=6))
+    with torch.no_grad():
+        y = net(x).numpy()
+    np.savez_compressed(os.path.join(OUT, "hrnet_w48_gaussian.npz"), out=y)
+    print("w48", y.shape, "absmax", float(np.abs(y).max()), "std", float(y.std()))
+
+
 def gen_decode(inference):
     c, s = synth.synth_center_scale(4, seed=2)
     out = {"center": c, "scale": s}
@@ -275,6 +296,10 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     pose_hrnet, inference, loss, transforms, jd = load_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "w48":
+        gen_hrnet_w48(pose_hrnet)
+        return
+    gen_hrnet_w48(pose_hrnet)
     gen_flip(transforms)
     gen_data(jd)
     gen_loss(loss)

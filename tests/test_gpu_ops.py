@@ -102,6 +102,11 @@ CONV_CASES = [
     (1, 1, 128, 32, 16, 12, 3, False, False, 0),   # fuse 1x1 (low-res temp)
     (1, 1, 32, 128, 64, 48, 2, True, False, 3),    # last-module f_00 + three upsampled terms
     (3, 1, 32, 32, 8, 8, 1, False, False, 0),      # single tiny image
+    (3, 1, 48, 48, 96, 72, 2, True, True, 0),      # W48 branch 0 at 384x288: ragged K chunk (48 = 32 + 16), 2 column tiles
+    (3, 1, 96, 96, 48, 36, 2, True, True, 0),      # W48 branch 1
+    (3, 2, 48, 96, 96, 72, 2, True, True, 1),      # W48 fuse chain end
+    (1, 1, 192, 48, 24, 18, 2, False, False, 0),   # W48 fuse 1x1
+    (3, 1, 16, 16, 24, 16, 2, True, True, 0),      # width-16 mini net of the reference fixture
 ]
 
 
@@ -133,7 +138,7 @@ def test_conv_rejects_bad_shapes():
     t = torch.zeros(8 * 8 * 32, device="cuda")
     rc = _lib.lib().udp_conv2d_fused(C.byref(op), _lib.UDP_F32, 1, _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), None, None,
                                      None, None, _lib.ptr(t), _lib.stream_ptr())
-    assert rc == -3 and b"multiple of 32" in _lib.lib().udp_last_error()
+    assert rc == -3 and b"multiple of 16" in _lib.lib().udp_last_error()
     rc = _lib.lib().udp_conv2d_fused(C.byref(op), _lib.UDP_F32, 1, None, None, None, None, None, None, None, None, None)
     assert rc == -1
 

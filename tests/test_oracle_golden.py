@@ -172,3 +172,15 @@ def test_w32_matches_reference(golden_dir):
     x = torch.from_numpy(synth.synth_crops(1, 256, 192, seed=5))
     y = ohrnet.hrnet_forward(sd, synth.W32_EXTRA, x).numpy()
     np.testing.assert_allclose(y, g["out"][:1], rtol=0, atol=1e-4)
+
+
+def test_w48_384x288_matches_reference(golden_dir):
+    """Config 4 network (widths 48/96/192/384, 384x288 input): oracle == reference module."""
+    g = _g(golden_dir, "hrnet_w48_gaussian.npz")
+    calib = dict(_g(golden_dir, "bn_calib_w48_gaussian.npz"))
+    extra = synth.scaled_extra(48)
+    sd = synth.synth_state_dict(extra, 17, "gaussian", seed=2, bn_calib=calib)
+    x = torch.from_numpy(synth.synth_crops(1, 384, 288, seed=6))
+    y = ohrnet.hrnet_forward(sd, extra, x).numpy()
+    assert y.shape == (1, 17, 96, 72)
+    np.testing.assert_allclose(y, g["out"], rtol=0, atol=1e-5)

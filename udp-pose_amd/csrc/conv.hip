@@ -213,7 +213,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
   const int in_groups = (npix_in + 15) >> 4;
   const int in_bytes = in_groups * 16 * ROWB;
   const int stage_bytes = in_bytes + TAPS * BN * ROWB;
-  const int nchunks = p.Cin / CK;
+  const int nchunks = (p.Cin + CK - 1) / CK;
+  const bool ragged = (p.Cin % CK) != 0;   // last chunk is partly past Cin: those 16-byte parts read zeros
   const int RT = p.R * p.TW;
   const int M = p.G * RT;
   const unsigned cinb = (unsigned)p.Cin * ESZ;
@@ -252,18 +253,26 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
   // weights: LDS row (tap, nb*16 + r) holds cout 4*NB*(r>>2) + 4*nb + (r&3) of this block
   auto stage = [&](int c, unsigned char* sb) {
     const unsigned coff = (unsigned)c * (CK * ESZ);
+    const bool cut = ragged && c == nchunks - 1;           // wave-uniform
+    const int parts_left = (p.Cin - c * CK) / (16 / ESZ);  // 16-byte parts of this chunk that exist
 #pragma unroll
     for (int i = 0; i < MAXG; ++i) {
       const int gidx = wave + 4 * i;
-      if (gidx < in_groups) blds16(r_in, src_off[i] + coff, sb + gidx * (16 * ROWB));
+      if (gidx < in_groups) {
+        unsigned off = src_off[i] + coff;
+        if (cut && (spart ^ swz(gidx * 16 + srow)) >= parts_left) off = kOobOff;
+        blds16(r_in, off, sb + gidx * (16 * ROWB));
+      }
     }
     for (int gidx = wave; gidx < WGROUPS; gidx += 4) {
       const int wr = gidx * 16 + srow;
       const int tap = wr / BN;   // BN is a power of two
       const int rho = wr & (BN - 1);
       const int co = (4 * NB) * ((rho & 15) >> 2) + 4 * (rho >> 4) + (rho & 3);
-      const unsigned e = __umul24(__umul24(tap, p.CoutPad) + cb * BN + co, cinb) + coff;
-      blds16(r_w, e + ((spart ^ swz(wr)) << 4), sb + in_bytes + gidx * (16 * ROWB));
+      const int lp = spart ^ swz(wr);
+      unsigned e = __umul24(__umul24(tap, p.CoutPad) + cb * BN + co, cinb) + coff + (lp << 4);
+      if (cut && lp >= parts_left) e = kOobOff;
+      blds16(r_w, e, sb + in_bytes + gidx * (16 * ROWB));
     }
   };
 
@@ -722,7 +731,7 @@ static int largest_divisor_leq(int n, int lim) {
 size_t conv_choose_tile(ConvParams& p, int ks, int stride, int dtype, int* nb_out) {
   const int kMaxM = 256;
   const int ck = dtype == UDP_F32 ? 16 : 32;
-  const int nstage = p.Cin / ck > 1 ? 2 : 1;
+  const int nstage = ceil_div(p.Cin, ck) > 1 ? 2 : 1;
   int TW = p.Wout;
   while (TW > 64) TW = (TW + 1) / 2;
   int maxR = kMaxM / TW;
@@ -863,7 +872,7 @@ static int describe_persist(const ConvParams& p, int ks, int stride, int nb, int
 
 // Fills `out` with the kernel, grid and arguments of one fused conv (tile choice included).
 int describe_conv(ConvParams p, int dtype, int ks, int stride, Launch* out) {
-  if (p.Cin % 32 != 0) return fail(UDP_ERR_UNSUPPORTED, "conv Cin=%d is not a multiple of 32", p.Cin);
+  if (p.Cin % 16 != 0) return fail(UDP_ERR_UNSUPPORTED, "conv Cin=%d is not a multiple of 16", p.Cin);
   if (!p.out_nchw_f32 && p.Cout % 16 != 0)
     return fail(UDP_ERR_UNSUPPORTED, "NHWC conv Cout=%d is not a multiple of 16", p.Cout);
   const size_t esz = dtype == UDP_F32 ? 4 : 2;
