@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UDP_POSE_ABI_VERSION 2
+#define UDP_POSE_ABI_VERSION 3
 
 enum udp_status {
   UDP_OK = 0,
@@ -60,7 +60,10 @@ const char* udp_last_error(void);
 enum udp_op_kind {
   UDP_OP_STEM = 0, /* 3x3 s2 conv, Cin=3, reads the NCHW fp32 network input    */
   UDP_OP_CONV = 1, /* implicit-GEMM conv on MFMA, ks 1|3, stride 1|2           */
-  UDP_OP_FUSE = 2  /* no conv: out = act(in + sum_k nearest_up(up_k))          */
+  UDP_OP_FUSE = 2, /* no conv: out = act(in [+ res] + sum_k nearest_up(up_k))  */
+  UDP_OP_STEM7 = 3,   /* 7x7 s2 p3 conv, Cin=3, reads the NCHW fp32 network input (RSN top) */
+  UDP_OP_MAXPOOL = 4, /* MaxPool2d(3, stride 2, pad 1) */
+  UDP_OP_BILINEAR = 5 /* bilinear resize, align_corners=True, hin x win -> hout x wout */
 };
 
 #define UDP_MAX_LANES 4
@@ -82,6 +85,11 @@ typedef struct udp_conv_op {
   int64_t w_off;           /* byte offset in the weight blob: [ks*ks][cout_pad][cin] in dtype
                               (UDP_OP_STEM: fp32 [27][cout]) */
   int64_t b_off;           /* byte offset of the fp32 bias [cout_pad] */
+  /* Channel-slice views (elements; 0 pitch = dense): the op reads channels [in_coff, in_coff+cin) of
+   * a tensor stored with in_pitch channels per pixel, writes [out_coff, out_coff+cout) of a tensor with
+   * out_pitch channels, likewise for res.  torch.split / torch.cat of the RSN bottleneck
+   * (RSN/exps/RSN18.coco/network.py:102-114) become views, never copies. */
+  int32_t in_coff, in_pitch, out_coff, out_pitch, res_coff, res_pitch;
   int32_t lane;            /* 0..UDP_MAX_LANES-1: ops of different lanes may run concurrently
                               (HRNet branches); lane 0 runs on the caller's stream */
   int32_t n_wait;          /* cross-lane dependencies: this op starts after ops wait_op[0..n_wait) */
@@ -132,6 +140,10 @@ int udp_conv2d_fused(const udp_conv_op* op_host, int dtype, int n, const void* i
  * ------------------------------------------------------------------------- */
 int udp_flip_fuse(const float* a, const float* b, const int32_t* src_ch, const float* sign,
                   int n, int c, int h, int w, float* out, void* stream);
+/* Same, followed by a division: out = ((a + flip_back(b)) * 0.5f) / divisor.  The RSN test loop
+ * divides the fused maps by 255 before decoding (RSN/exps/RSN18.coco.e1.se.36x8x132000_prm/test.py:174-185). */
+int udp_flip_fuse_scaled(const float* a, const float* b, const int32_t* src_ch, const float* sign,
+                         int n, int c, int h, int w, float divisor, float* out, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * UDP decode.  Replaces get_final_preds (deep_hrnet/lib/core/inference.py:149-186):

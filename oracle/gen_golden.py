@@ -183,6 +183,36 @@ def gen_hrnet_w48(pose_hrnet):
     print("w48", y.shape, "absmax", float(np.abs(y).max()), "std", float(y.std()))
 
 
+def gen_rsn18():
+    """Config 5 backbone: RSN-18 (RSN/exps/RSN18.coco/network.py), 17-channel and 51-channel heads."""
+    from oracle import rsn as o_rsn
+    sys.path.insert(0, "/root/reference/RSN")
+    net_mod = _load("ref_rsn_network", "/root/reference/RSN/exps/RSN18.coco/network.py")
+    for och in (17, 51):
+        cfg = AttrDict({"MODEL": {"STAGE_NUM": 1, "UPSAMPLE_CHANNEL_NUM": 256}, "DATASET": {"KEYPOINT": {"NUM": och}},
+                        "OUTPUT_SHAPE": (64, 48), "LOSS": {"OHKM": True, "TOPK": 8, "COARSE_TO_FINE": True}})
+        net = net_mod.RSN(cfg)
+        net.eval()
+        keys = {k: list(v.shape) for k, v in net.state_dict().items()}
+        with open(os.path.join(OUT, "rsn18_keys_%d.json" % och), "w") as f:
+            json.dump(keys, f)
+        sd = synth.synth_rsn18_state_dict(och, seed=4)
+        xc = torch.from_numpy(synth.synth_crops(24, 256, 192, seed=15))    # 8x6 maps at the deepest level: many crops
+        yc = o_rsn.rsn_forward(sd, xc, calibrate=True)
+        calib = {k: v.numpy().astype(np.float16).astype(np.float32) if "running_mean" in k else v.numpy()
+                 for k, v in sd.items() if "running_" in k}
+        calib["final.scale"] = np.float32(0.25 / float(yc.std()))
+        np.savez_compressed(os.path.join(OUT, "bn_calib_rsn18_%d.npz" % och),
+                            **{k: (v.astype(np.float16) if "running_mean" in k else v) for k, v in calib.items()})
+        sd = synth.synth_rsn18_state_dict(och, seed=4, bn_calib=calib)
+        net.load_state_dict(sd, strict=True)
+        x = torch.from_numpy(synth.synth_crops(1, 256, 192, seed=8))
+        with torch.no_grad():
+            y = net(x).numpy()
+        np.savez_compressed(os.path.join(OUT, "rsn18_%d.npz" % och), out=y)
+        print("rsn18", och, y.shape, "absmax", float(np.abs(y).max()), "std", float(y.std()))
+
+
 def gen_decode(inference):
     c, s = synth.synth_center_scale(4, seed=2)
     out = {"center": c, "scale": s}
@@ -299,7 +329,11 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "w48":
         gen_hrnet_w48(pose_hrnet)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "rsn":
+        gen_rsn18()
+        return
     gen_hrnet_w48(pose_hrnet)
+    gen_rsn18()
     gen_flip(transforms)
     gen_data(jd)
     gen_loss(loss)

@@ -184,3 +184,18 @@ def test_w48_384x288_matches_reference(golden_dir):
     y = ohrnet.hrnet_forward(sd, extra, x).numpy()
     assert y.shape == (1, 17, 96, 72)
     np.testing.assert_allclose(y, g["out"], rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("och", [17, 51])
+def test_rsn18_matches_reference(golden_dir, och):
+    """Config 5 backbone: oracle RSN-18 == reference module; state_dict contract."""
+    from oracle import rsn as orsn
+    with open(os.path.join(golden_dir, "rsn18_keys_%d.json" % och)) as f:
+        ref = json.load(f)
+    ours = synth.rsn18_param_shapes(och)
+    assert list(ours.keys()) == list(ref.keys()) and all(list(ours[k]) == ref[k] for k in ours)
+    calib = dict(_g(golden_dir, "bn_calib_rsn18_%d.npz" % och))
+    sd = synth.synth_rsn18_state_dict(och, seed=4, bn_calib=calib)
+    x = torch.from_numpy(synth.synth_crops(1, 256, 192, seed=8))
+    y = orsn.rsn_forward(sd, x).numpy()
+    np.testing.assert_allclose(y, _g(golden_dir, "rsn18_%d.npz" % och)["out"], rtol=0, atol=1e-5)

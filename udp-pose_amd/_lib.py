@@ -12,9 +12,9 @@ LIB_PATH = os.path.join(_HERE, "libudp_pose_hip.so")
 
 UDP_OK = 0
 UDP_F32, UDP_BF16 = 0, 1
-UDP_OP_STEM, UDP_OP_CONV, UDP_OP_FUSE = 0, 1, 2
+UDP_OP_STEM, UDP_OP_CONV, UDP_OP_FUSE, UDP_OP_STEM7, UDP_OP_MAXPOOL, UDP_OP_BILINEAR = 0, 1, 2, 3, 4, 5
 UDP_BUF_NONE, UDP_BUF_OUTPUT = -1, -2
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_LANES, MAX_WAIT = 4, 8
 
 
@@ -27,6 +27,8 @@ class ConvOp(C.Structure):
         ("in_buf", C.c_int32), ("out_buf", C.c_int32), ("res_buf", C.c_int32),
         ("n_up", C.c_int32), ("up_buf", C.c_int32 * 3), ("up_shift", C.c_int32 * 3),
         ("w_off", C.c_int64), ("b_off", C.c_int64),
+        ("in_coff", C.c_int32), ("in_pitch", C.c_int32), ("out_coff", C.c_int32), ("out_pitch", C.c_int32),
+        ("res_coff", C.c_int32), ("res_pitch", C.c_int32),
         ("lane", C.c_int32), ("n_wait", C.c_int32), ("wait_op", C.c_int32 * 8),
     ]
 
@@ -51,6 +53,7 @@ _SIGS = {
     "udp_hrnet_flops_per_image": (C.c_double, [_P]),
     "udp_conv2d_fused": (C.c_int, [C.POINTER(ConvOp), C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "udp_flip_fuse": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "udp_flip_fuse_scaled": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P]),
     "udp_decode_gaussian": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int,
                                       _P, _P, _P, _P, _P]),
     "udp_decode_offset": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_float,

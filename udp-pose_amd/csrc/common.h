@@ -44,6 +44,7 @@ struct ConvParams {
   int up_shift[3];
   int nup;
   int N, Hin, Win, Cin, Hout, Wout, Cout, CoutPad;
+  int in_pitch, in_coff, out_pitch, out_coff, res_pitch, res_coff;   // channel-slice views (elements); pitch = channels per pixel of the stored tensor
   int G, R, TW;          // tile = G images x R rows x TW cols of output
   int IH, IW;            // input halo tile per image
   int tiles_x, tiles_y;  // tiles per image group

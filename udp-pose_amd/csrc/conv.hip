@@ -217,17 +217,19 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
   const bool ragged = (p.Cin % CK) != 0;   // last chunk is partly past Cin: those 16-byte parts read zeros
   const int RT = p.R * p.TW;
   const int M = p.G * RT;
-  const unsigned cinb = (unsigned)p.Cin * ESZ;
+  const unsigned cinb = (unsigned)p.Cin * ESZ;          // weight row
+  const unsigned inpb = (unsigned)p.in_pitch * ESZ;     // input pixel (the conv may read a channel slice)
+  const unsigned outpb = (unsigned)p.out_pitch * ESZ, respb = (unsigned)p.res_pitch * ESZ;
 
   const unsigned out_pix = (unsigned)p.N * p.Hout * p.Wout;
   const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<void*>(p.in), 0, (unsigned)p.N * p.Hin * p.Win * cinb, 0x00020000);
+      const_cast<void*>(p.in), 0, (unsigned)p.N * p.Hin * p.Win * inpb, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void*>(p.wgt), 0, (unsigned)TAPS * p.CoutPad * cinb, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(
-      p.out, 0, out_pix * p.Cout * (NCHW ? 4 : ESZ), 0x00020000);
+      p.out, 0, NCHW ? out_pix * p.Cout * 4 : out_pix * outpb, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<void*>(p.res), 0, p.res ? out_pix * p.Cout * ESZ : 0, 0x00020000);
+      const_cast<void*>(p.res), 0, p.res ? out_pix * respb : 0, 0x00020000);
 
   // ---- per-lane DMA offsets of the input halo tile (chunk 0); masked rows -> kOobOff -> zeros
   const int srow = lane >> 2;  // row inside a 16-row group
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
       const int n = n0 + g, gy = gy0 + iy, gx = gx0 + ix;
       const bool ok = row < npix_in && n < p.N && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win;
       const unsigned pix = __umul24(__umul24(n, p.Hin) + gy, p.Win) + gx;
-      off = ok ? pix * cinb + ((spart ^ swz(row)) << 4) : kOobOff;
+      off = ok ? pix * inpb + p.in_coff * ESZ + ((spart ^ swz(row)) << 4) : kOobOff;
     }
     src_off[i] = off;
   }
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
 
   // ---- the lane's MBW output pixels
   int prow[MBW];        // LDS row of the pixel's (0,0) tap
-  unsigned ooff[MBW];   // byte offset of its 4*NB-channel vector in the NHWC output (kOobOff = masked)
+  int opix[MBW];        // output pixel index, -1 = masked lane
   int ocrd[MBW];        // y | x << 10 | n << 20 (for the up-sampled addends / the NCHW form)
   const int cbase = cb * BN + 4 * NB * kg;
 #pragma unroll
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     const int n = n0 + g, y = y0 + r, xo = x0 + x;
     const bool ok = m0 < M && n < p.N && y < p.Hout && xo < p.Wout && (NCHW || cbase < p.Cout);
     const unsigned pix = __umul24(__umul24(n, p.Hout) + y, p.Wout) + xo;
-    ooff[i] = ok ? (pix * p.Cout + cbase) * (unsigned)ESZ : kOobOff;
+    opix[i] = ok ? (int)pix : -1;
     ocrd[i] = ok ? (y | (xo << 10) | (n << 20)) : -1;
   }
   const int wswz = swz(li);  // weight rows: (tap*BN + nb*16) is a multiple of 16 -> swizzle depends on li only
@@ -385,7 +387,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, f), r_out, off, 0, 0);
         }
     } else {
-      if (p.res) add_vec_buf<T, NB>(v, r_res, ooff[i]);
+      const unsigned ooff = opix[i] >= 0 ? (unsigned)opix[i] * outpb + (p.out_coff + cbase) * ESZ : kOobOff;
+      if (p.res) add_vec_buf<T, NB>(v, r_res, opix[i] >= 0 ? (unsigned)opix[i] * respb + (p.res_coff + cbase) * ESZ : kOobOff);
       if (p.nup) {   // wave-uniform, rare (exchange-unit outputs only)
         const int crd = ocrd[i];
         const int y = crd & 1023, xo = (crd >> 10) & 1023, n = crd >> 20;
@@ -404,7 +407,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[nb][q] = v[nb][q] > 0.f ? v[nb][q] : 0.f;
       }
-      store_vec_buf<T, NB>(r_out, ooff[i], v);
+      store_vec_buf<T, NB>(r_out, ooff, v);
     }
   }
   UDP_STAMP(6);
@@ -704,7 +707,8 @@ __global__ __launch_bounds__(256) void fuse_sum_kernel(const ConvParams p) {
     const long t2 = pix / p.Wout;
     const int y = t2 % p.Hout;
     const int n = t2 / p.Hout;
-    f32x4 v = load4<T>(reinterpret_cast<const T*>(p.in) + pix * p.Cout + c);
+    f32x4 v = load4<T>(reinterpret_cast<const T*>(p.in) + pix * p.in_pitch + p.in_coff + c);
+    if (p.res) v += load4<T>(reinterpret_cast<const T*>(p.res) + pix * p.res_pitch + p.res_coff + c);
     for (int u = 0; u < p.nup; ++u) {
       const int s = p.up_shift[u];
       const size_t up_pix = ((size_t)(n * (p.Hout >> s) + (y >> s)) * (p.Wout >> s) + (xo >> s));
@@ -714,7 +718,125 @@ __global__ __launch_bounds__(256) void fuse_sum_kernel(const ConvParams p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.f;
     }
-    store4<T>(reinterpret_cast<T*>(p.out) + pix * p.Cout + c, v);
+    store4<T>(reinterpret_cast<T*>(p.out) + pix * p.out_pitch + p.out_coff + c, v);
+  }
+}
+
+// RSN stem (RSN/exps/RSN18.coco/network.py:125-137): 7x7 stride-2 pad-3 conv on the NCHW fp32 input
+// (Cin = 3, 147 taps, direct VALU form) + folded BN + ReLU -> NHWC.  Same thread layout as
+// stem_conv_kernel: 64 pixels x 4 groups of 16 output channels per workgroup; weights [ky][kx][ci][64].
+template <typename T>
+__global__ __launch_bounds__(256, 4) void stem7_conv_kernel(const ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) float w7_s[];   // 147*64 weights + 64 bias
+  const int tid = threadIdx.x;
+  const float* wg = reinterpret_cast<const float*>(p.wgt);
+  for (int i = tid; i < 147 * 64; i += 256) w7_s[i] = wg[i];
+  if (tid < 64) w7_s[147 * 64 + tid] = p.bias[tid];
+  __syncthreads();
+  const int cg = tid & 3;
+  const long pix = (long)blockIdx.x * 64 + (tid >> 2);
+  const long total = (long)p.N * p.Hout * p.Wout;
+  if (pix >= total) return;
+  const int xo = pix % p.Wout;
+  const long t2 = pix / p.Wout;
+  const int yo = t2 % p.Hout;
+  const int n = t2 / p.Hout;
+  const bool mirror = n >= p.flip_from;
+  const int ns = mirror ? n - p.flip_from : n;
+  const float* in = reinterpret_cast<const float*>(p.in) + (size_t)ns * 3 * p.Hin * p.Win;
+  float acc[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = w7_s[147 * 64 + cg * 16 + q];
+#pragma unroll 1
+  for (int tap = 0; tap < 49; ++tap) {
+    const int ky = tap / 7, kx = tap - ky * 7;
+    const int gy = yo * 2 - 3 + ky;
+    const int gx = xo * 2 - 3 + kx;
+    const bool ok = gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win;
+    const int sx = mirror ? p.Win - 1 - gx : gx;
+    const float* wr = &w7_s[tap * 3 * 64 + cg * 16];
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci) {
+      const float v = ok ? in[((size_t)ci * p.Hin + gy) * p.Win + sx] : 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; q += 4) {
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + ci * 64 + q);
+        acc[q + 0] = fmaf(v, w4[0], acc[q + 0]);
+        acc[q + 1] = fmaf(v, w4[1], acc[q + 1]);
+        acc[q + 2] = fmaf(v, w4[2], acc[q + 2]);
+        acc[q + 3] = fmaf(v, w4[3], acc[q + 3]);
+      }
+    }
+  }
+  T* o = reinterpret_cast<T*>(p.out) + (size_t)pix * 64 + cg * 16;
+#pragma unroll
+  for (int q = 0; q < 16; q += 4) {
+    f32x4 v = {acc[q], acc[q + 1], acc[q + 2], acc[q + 3]};
+    if (p.relu) {
+#pragma unroll
+      for (int z = 0; z < 4; ++z) v[z] = v[z] > 0.f ? v[z] : 0.f;
+    }
+    store4<T>(o + q, v);
+  }
+}
+
+// MaxPool2d(3, stride 2, pad 1) on NHWC (network.py:131,136); padding never wins (-inf).
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool3_kernel(const ConvParams p) {
+  const int C4 = p.Cout >> 2;
+  const long total = (long)p.N * p.Hout * p.Wout * C4;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c = (idx % C4) * 4;
+    const long pix = idx / C4;
+    const int xo = pix % p.Wout;
+    const long t2 = pix / p.Wout;
+    const int y = t2 % p.Hout;
+    const int n = t2 / p.Hout;
+    f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int ky = 0; ky < 3; ++ky) {
+      const int gy = y * 2 - 1 + ky;
+      if (gy < 0 || gy >= p.Hin) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        const int gx = xo * 2 - 1 + kx;
+        if (gx < 0 || gx >= p.Win) continue;
+        const f32x4 v = load4<T>(reinterpret_cast<const T*>(p.in) + ((size_t)(n * p.Hin + gy) * p.Win + gx) * p.in_pitch + p.in_coff + c);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) m[q] = v[q] > m[q] ? v[q] : m[q];
+      }
+    }
+    store4<T>(reinterpret_cast<T*>(p.out) + pix * p.out_pitch + p.out_coff + c, m);
+  }
+}
+
+// F.interpolate(mode='bilinear', align_corners=True) on NHWC (network.py:246-255): src = dst*(in-1)/(out-1),
+// fp32 weights like ATen's upsample_bilinear2d.
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_ac_kernel(const ConvParams p) {
+  const int C4 = p.Cout >> 2;
+  const long total = (long)p.N * p.Hout * p.Wout * C4;
+  const float sy = p.Hout > 1 ? (float)(p.Hin - 1) / (float)(p.Hout - 1) : 0.f;
+  const float sx = p.Wout > 1 ? (float)(p.Win - 1) / (float)(p.Wout - 1) : 0.f;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c = (idx % C4) * 4;
+    const long pix = idx / C4;
+    const int xo = pix % p.Wout;
+    const long t2 = pix / p.Wout;
+    const int y = t2 % p.Hout;
+    const int n = t2 / p.Hout;
+    const float fy = sy * (float)y, fx = sx * (float)xo;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < p.Hin - 1 ? 1 : 0), x1 = x0 + (x0 < p.Win - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const T* base = reinterpret_cast<const T*>(p.in) + (size_t)n * p.Hin * p.Win * p.in_pitch + p.in_coff + c;
+    const f32x4 v00 = load4<T>(base + ((size_t)y0 * p.Win + x0) * p.in_pitch);
+    const f32x4 v01 = load4<T>(base + ((size_t)y0 * p.Win + x1) * p.in_pitch);
+    const f32x4 v10 = load4<T>(base + ((size_t)y1 * p.Win + x0) * p.in_pitch);
+    const f32x4 v11 = load4<T>(base + ((size_t)y1 * p.Win + x1) * p.in_pitch);
+    f32x4 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = hy * (hx * v00[q] + lx * v01[q]) + ly * (hx * v10[q] + lx * v11[q]);
+    store4<T>(reinterpret_cast<T*>(p.out) + pix * p.out_pitch + p.out_coff + c, v);
   }
 }
 
@@ -815,7 +937,7 @@ static int describe_conv_t(const ConvParams& p, int ks, int stride, int nb, int 
 #define UDP_CASE_OUT(K, S, B)                                                          \
   if (ks == K && stride == S && nb == B && p.out_nchw_f32) return describe_mbw<T, K, S, B, true>(p, mbw, lds, out);
   UDP_CASE(3, 1, 2) UDP_CASE(3, 1, 4) UDP_CASE(3, 2, 2) UDP_CASE(3, 2, 4)
-  UDP_CASE(1, 1, 2) UDP_CASE(1, 1, 4)
+  UDP_CASE(1, 1, 2) UDP_CASE(1, 1, 4) UDP_CASE(1, 2, 2) UDP_CASE(1, 2, 4)
   UDP_CASE_OUT(1, 1, 2) UDP_CASE_OUT(1, 1, 4) UDP_CASE_OUT(3, 1, 2) UDP_CASE_OUT(3, 1, 4)
 #undef UDP_CASE
 #undef UDP_CASE_OUT
@@ -854,6 +976,8 @@ static int describe_persist_mbw(const ConvParams& p, int mbw, size_t lds, int gr
 static int describe_persist(const ConvParams& p, int ks, int stride, int nb, int mbw, Launch* out) {
   const int npix = p.G * p.IH * p.IW;
   if (p.out_nchw_f32 || p.Cin != 32 || npix > MAXGP * 64 || p.ntiles >= 65536) return 1;
+  if (p.in_pitch != p.Cin || p.in_coff || p.out_pitch != p.Cout || p.out_coff || (p.res && (p.res_pitch != p.Cout || p.res_coff)))
+    return 1;                                         // channel-slice views: generic kernel
   const size_t lds = (size_t)(ks * ks * nb * 16 + 2 * ((npix + 15) / 16) * 16) * ROWB;
   int per_cu = (int)((150 * 1024) / lds);
   if (per_cu > 4) per_cu = 4;
@@ -876,7 +1000,12 @@ int describe_conv(ConvParams p, int dtype, int ks, int stride, Launch* out) {
   if (!p.out_nchw_f32 && p.Cout % 16 != 0)
     return fail(UDP_ERR_UNSUPPORTED, "NHWC conv Cout=%d is not a multiple of 16", p.Cout);
   const size_t esz = dtype == UDP_F32 ? 4 : 2;
-  if ((size_t)p.N * p.Hin * p.Win * p.Cin * esz >= 0x7FFF0000u || (size_t)p.N * p.Hout * p.Wout * p.Cout * 4 >= 0x7FFF0000u ||
+  if ((size_t)p.N * p.Hin * p.Win * p.in_pitch * esz >= 0x7FFF0000u || (size_t)p.N * p.Hout * p.Wout * p.out_pitch * 4 >= 0x7FFF0000u ||
+      (p.in_coff * esz) % 16 || (p.in_pitch * esz) % 16 ||
+      (!p.out_nchw_f32 && ((p.out_coff * esz) % 16 || (p.out_pitch * esz) % 16)) ||
+      (p.res && ((p.res_coff * esz) % 16 || (p.res_pitch * esz) % 16)))
+    return fail(UDP_ERR_UNSUPPORTED, "conv channel views must be 16-byte aligned and tensors < 2 GiB");
+  if (false ||
       p.N >= 2048)
     return fail(UDP_ERR_UNSUPPORTED, "conv tensor exceeds the 2 GiB the 32-bit buffer offsets cover; split the batch");
   int nb = 2;
@@ -924,6 +1053,40 @@ extern "C" int udp_debug_set_stamps(unsigned long long* dev_buf) {
   return UDP_OK;
 }
 #endif
+
+template <typename KF, typename KB>
+static int describe_elementwise(const ConvParams& p, int dtype, KF kf, KB kb, Launch* out) {
+  if (p.Cout % 4 != 0) return fail(UDP_ERR_UNSUPPORTED, "element-wise op: C=%d is not a multiple of 4", p.Cout);
+  const long total = (long)p.N * p.Hout * p.Wout * (p.Cout / 4);
+  long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  out->fn = dtype == UDP_F32 ? reinterpret_cast<const void*>(kf) : reinterpret_cast<const void*>(kb);
+  out->grid = dim3((unsigned)blocks);
+  out->block = dim3(256);
+  out->lds = 0;
+  out->p = p;
+  return UDP_OK;
+}
+
+int describe_maxpool(const ConvParams& p, int dtype, Launch* out) {
+  return describe_elementwise(p, dtype, &maxpool3_kernel<float>, &maxpool3_kernel<__bf16>, out);
+}
+
+int describe_bilinear(const ConvParams& p, int dtype, Launch* out) {
+  return describe_elementwise(p, dtype, &bilinear_ac_kernel<float>, &bilinear_ac_kernel<__bf16>, out);
+}
+
+int describe_stem7(const ConvParams& p, int dtype, Launch* out) {
+  if (p.Cout != 64) return fail(UDP_ERR_UNSUPPORTED, "7x7 stem expects 64 output channels, got %d", p.Cout);
+  const long total = (long)p.N * p.Hout * p.Wout;
+  out->fn = dtype == UDP_F32 ? reinterpret_cast<const void*>(&stem7_conv_kernel<float>)
+                             : reinterpret_cast<const void*>(&stem7_conv_kernel<__bf16>);
+  out->grid = dim3((unsigned)((total + 63) / 64));
+  out->block = dim3(256);
+  out->lds = (147 * 64 + 64) * sizeof(float);
+  out->p = p;
+  return UDP_OK;
+}
 
 int run_launch(const Launch& l, hipStream_t s) {
   void* args[] = {const_cast<ConvParams*>(&l.p)};

@@ -284,7 +284,8 @@ __global__ __launch_bounds__(256) void flip_fuse_kernel(const float* __restrict_
                                                         const float* __restrict__ b,
                                                         const int* __restrict__ src_ch,
                                                         const float* __restrict__ sign, int c, int h,
-                                                        int w, long total, float* __restrict__ out) {
+                                                        int w, long total, float divisor,
+                                                        float* __restrict__ out) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int x = i % w;
     long t = i / w;
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(256) void flip_fuse_kernel(const float* __restrict_
     const int ch = t % c;
     const long n = t / c;
     const float fb = b[((n * c + src_ch[ch]) * h + y) * w + (w - 1 - x)] * sign[ch];
-    out[i] = (a[i] + fb) * 0.5f;
+    out[i] = (a[i] + fb) * 0.5f / divisor;   // divisor 1 (exact) or RSN's 255 (test.py:185)
   }
 }
 
@@ -379,16 +380,21 @@ extern "C" int udp_decode_offset(const float* heatmaps, int n, int j, int h, int
   return UDP_OK;
 }
 
-extern "C" int udp_flip_fuse(const float* a, const float* b, const int32_t* src_ch, const float* sign, int n,
-                             int c, int h, int w, float* out, void* stream) {
+extern "C" int udp_flip_fuse_scaled(const float* a, const float* b, const int32_t* src_ch, const float* sign, int n,
+                                    int c, int h, int w, float divisor, float* out, void* stream) {
   if (!a || !b || !src_ch || !sign || !out) return fail(UDP_ERR_ARG, "udp_flip_fuse: null pointer");
-  if (n < 0 || c <= 0 || h <= 0 || w <= 0) return fail(UDP_ERR_ARG, "udp_flip_fuse: bad shape");
+  if (n < 0 || c <= 0 || h <= 0 || w <= 0 || !(divisor > 0.f)) return fail(UDP_ERR_ARG, "udp_flip_fuse: bad shape / divisor");
   const long total = (long)n * c * h * w;
   if (total == 0) return UDP_OK;
   long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(flip_fuse_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, src_ch,
-                     sign, c, h, w, total, out);
+                     sign, c, h, w, total, divisor, out);
   UDP_HIP_CHECK(hipGetLastError());
   return UDP_OK;
+}
+
+extern "C" int udp_flip_fuse(const float* a, const float* b, const int32_t* src_ch, const float* sign, int n,
+                             int c, int h, int w, float* out, void* stream) {
+  return udp_flip_fuse_scaled(a, b, src_ch, sign, n, c, h, w, 1.0f, out, stream);
 }

@@ -11,6 +11,9 @@ namespace udp {
 int describe_conv(ConvParams p, int dtype, int ks, int stride, Launch* out);
 int describe_stem(const ConvParams& p, int dtype, Launch* out);
 int describe_fuse(const ConvParams& p, int dtype, Launch* out);
+int describe_stem7(const ConvParams& p, int dtype, Launch* out);
+int describe_maxpool(const ConvParams& p, int dtype, Launch* out);
+int describe_bilinear(const ConvParams& p, int dtype, Launch* out);
 int run_launch(const Launch& l, hipStream_t s);
 }  // namespace udp
 
@@ -49,8 +52,15 @@ static size_t esize(int dtype) { return dtype == UDP_F32 ? 4 : 2; }
 static int validate_op(const udp_hrnet* h, const udp_conv_op& o, int idx) {
   const int nb = (int)h->buf_elems.size();
   auto buf_ok = [&](int b, int64_t need) { return b >= 0 && b < nb && h->buf_elems[b] >= need; };
-  const int64_t out_need = (int64_t)o.hout * o.wout * o.cout;
-  if (o.kind < UDP_OP_STEM || o.kind > UDP_OP_FUSE) return fail(UDP_ERR_ARG, "op %d: bad kind %d", idx, o.kind);
+  const int64_t out_need = (int64_t)o.hout * o.wout * (o.out_pitch ? o.out_pitch : o.cout);
+  if (o.kind < UDP_OP_STEM || o.kind > UDP_OP_BILINEAR) return fail(UDP_ERR_ARG, "op %d: bad kind %d", idx, o.kind);
+  const bool is_stem = o.kind == UDP_OP_STEM || o.kind == UDP_OP_STEM7;
+  const bool has_w = is_stem || o.kind == UDP_OP_CONV;
+  const int ipitch = o.in_pitch ? o.in_pitch : o.cin, opitch = o.out_pitch ? o.out_pitch : o.cout;
+  const int rpitch = o.res_pitch ? o.res_pitch : o.cout;
+  if (o.in_coff < 0 || o.out_coff < 0 || o.res_coff < 0 || o.in_coff + o.cin > ipitch || o.out_coff + o.cout > opitch ||
+      o.res_coff + o.cout > rpitch)
+    return fail(UDP_ERR_ARG, "op %d: channel view outside its tensor", idx);
   if (o.cout <= 0 || o.hout <= 0 || o.wout <= 0 || o.cout_pad < o.cout || o.cout_pad % 32)
     return fail(UDP_ERR_ARG, "op %d: bad output shape / cout_pad", idx);
   if (o.out_buf == UDP_BUF_OUTPUT) {
@@ -61,19 +71,25 @@ static int validate_op(const udp_hrnet* h, const udp_conv_op& o, int idx) {
   } else if (!buf_ok(o.out_buf, out_need)) {
     return fail(UDP_ERR_ARG, "op %d: out_buf %d missing or too small", idx, o.out_buf);
   }
-  if (o.kind == UDP_OP_STEM) {
-    if (o.ks != 3 || o.stride != 2 || o.cin != 3 || o.hin != h->in_h || o.win != h->in_w)
-      return fail(UDP_ERR_ARG, "op %d: stem must be 3x3 s2 on the %dx%d input", idx, h->in_h, h->in_w);
+  if (is_stem) {
+    const int want = o.kind == UDP_OP_STEM ? 3 : 7;
+    if (o.ks != want || o.stride != 2 || o.cin != 3 || o.hin != h->in_h || o.win != h->in_w)
+      return fail(UDP_ERR_ARG, "op %d: stem must be %dx%d s2 on the %dx%d input", idx, want, want, h->in_h, h->in_w);
   } else {
-    if (!buf_ok(o.in_buf, (int64_t)o.hin * o.win * o.cin)) return fail(UDP_ERR_ARG, "op %d: in_buf %d missing or too small", idx, o.in_buf);
-    if (o.in_buf == o.out_buf) return fail(UDP_ERR_ARG, "op %d: in-place conv is not supported", idx);
+    if (!buf_ok(o.in_buf, (int64_t)o.hin * o.win * ipitch)) return fail(UDP_ERR_ARG, "op %d: in_buf %d missing or too small", idx, o.in_buf);
+    if (o.in_buf == o.out_buf && o.kind == UDP_OP_CONV && o.ks != 1) return fail(UDP_ERR_ARG, "op %d: in-place 3x3 conv is not supported", idx);
   }
-  if (o.kind != UDP_OP_FUSE) {
-    if ((o.ks != 1 && o.ks != 3) || (o.stride != 1 && o.stride != 2)) return fail(UDP_ERR_ARG, "op %d: ks/stride", idx);
+  if (o.kind == UDP_OP_MAXPOOL) {
+    if (o.cin != o.cout || o.hout != (o.hin + 2 - 3) / 2 + 1 || o.wout != (o.win + 2 - 3) / 2 + 1)
+      return fail(UDP_ERR_ARG, "op %d: maxpool 3x3 s2 p1 shape", idx);
+  } else if (o.kind == UDP_OP_BILINEAR) {
+    if (o.cin != o.cout) return fail(UDP_ERR_ARG, "op %d: bilinear resize keeps the channel count", idx);
+  } else if (has_w) {
+    if ((o.ks != 1 && o.ks != 3 && o.ks != 7) || (o.stride != 1 && o.stride != 2)) return fail(UDP_ERR_ARG, "op %d: ks/stride", idx);
     const int pad = o.ks / 2;
     if (o.hout != (o.hin + 2 * pad - o.ks) / o.stride + 1 || o.wout != (o.win + 2 * pad - o.ks) / o.stride + 1)
       return fail(UDP_ERR_ARG, "op %d: output size does not match input/stride", idx);
-    const size_t wbytes = o.kind == UDP_OP_STEM ? (size_t)27 * o.cout * 4
+    const size_t wbytes = is_stem ? (size_t)o.ks * o.ks * 3 * o.cout * 4
                                                 : (size_t)o.ks * o.ks * o.cout_pad * o.cin * esize(h->dtype);
     if (o.w_off < 0 || (size_t)o.w_off + wbytes > h->weights_bytes || (o.w_off & 15))
       return fail(UDP_ERR_ARG, "op %d: weight range outside the blob or misaligned", idx);
@@ -85,7 +101,7 @@ static int validate_op(const udp_hrnet* h, const udp_conv_op& o, int idx) {
   if (o.lane < 0 || o.lane >= UDP_MAX_LANES || o.n_wait < 0 || o.n_wait > UDP_MAX_WAIT) return fail(UDP_ERR_ARG, "op %d: lane/n_wait", idx);
   for (int k = 0; k < o.n_wait; ++k)
     if (o.wait_op[k] < 0 || o.wait_op[k] >= idx) return fail(UDP_ERR_ARG, "op %d: wait_op %d must name an earlier op", idx, o.wait_op[k]);
-  if (o.res_buf != UDP_BUF_NONE && !buf_ok(o.res_buf, out_need)) return fail(UDP_ERR_ARG, "op %d: res_buf", idx);
+  if (o.res_buf != UDP_BUF_NONE && !buf_ok(o.res_buf, (int64_t)o.hout * o.wout * rpitch)) return fail(UDP_ERR_ARG, "op %d: res_buf", idx);
   if (o.n_up < 0 || o.n_up > 3) return fail(UDP_ERR_ARG, "op %d: n_up", idx);
   for (int u = 0; u < o.n_up; ++u) {
     const int s = o.up_shift[u];
@@ -134,11 +150,11 @@ extern "C" int udp_hrnet_create(const udp_conv_op* ops, int n_ops, const int64_t
       return rc;
     }
     has_out |= ops[i].out_buf == UDP_BUF_OUTPUT;
-    if (ops[i].kind != UDP_OP_FUSE)
+    if (ops[i].kind == UDP_OP_STEM || ops[i].kind == UDP_OP_STEM7 || ops[i].kind == UDP_OP_CONV)
       h->flops += 2.0 * ops[i].ks * ops[i].ks * ops[i].cin * ops[i].cout * ops[i].hout * ops[i].wout;
     h->ops.push_back(ops[i]);
   }
-  if (!has_out || h->ops[0].kind != UDP_OP_STEM || h->ops[0].lane != 0 || h->ops.back().lane != 0 ||
+  if (!has_out || (h->ops[0].kind != UDP_OP_STEM && h->ops[0].kind != UDP_OP_STEM7) || h->ops[0].lane != 0 || h->ops.back().lane != 0 ||
       h->ops.back().out_buf != UDP_BUF_OUTPUT) {
     delete h;
     return fail(UDP_ERR_ARG, "udp_hrnet_create: program needs a stem op first and the output op last, both on lane 0");
@@ -192,7 +208,14 @@ static int describe_all(const udp_hrnet* h, const float* in, int n, int flip, ch
     p.CoutPad = o.cout_pad;
     p.relu = o.relu;
     p.flip_from = flip ? n : B;
-    p.in = o.kind == UDP_OP_STEM ? reinterpret_cast<const void*>(in) : buf(o.in_buf);
+    const bool is_stem = o.kind == UDP_OP_STEM || o.kind == UDP_OP_STEM7;
+    p.in_pitch = o.in_pitch ? o.in_pitch : o.cin;
+    p.in_coff = o.in_coff;
+    p.out_pitch = o.out_pitch ? o.out_pitch : o.cout;
+    p.out_coff = o.out_coff;
+    p.res_pitch = o.res_pitch ? o.res_pitch : o.cout;
+    p.res_coff = o.res_coff;
+    p.in = is_stem ? reinterpret_cast<const void*>(in) : buf(o.in_buf);
     p.out_nchw_f32 = o.out_buf == UDP_BUF_OUTPUT;
     p.out = p.out_nchw_f32 ? reinterpret_cast<void*>(out) : buf(o.out_buf);
     p.res = o.res_buf == UDP_BUF_NONE ? nullptr : buf(o.res_buf);
@@ -201,17 +224,19 @@ static int describe_all(const udp_hrnet* h, const float* in, int n, int flip, ch
       p.up[u] = buf(o.up_buf[u]);
       p.up_shift[u] = o.up_shift[u];
     }
-    if (o.kind != UDP_OP_FUSE) {
+    if (is_stem || o.kind == UDP_OP_CONV) {
       p.wgt = h->weights + o.w_off;
       p.bias = reinterpret_cast<const float*>(h->weights + o.b_off);
     }
     int rc;
-    if (o.kind == UDP_OP_STEM)
-      rc = describe_stem(p, h->dtype, &ls[i]);
-    else if (o.kind == UDP_OP_FUSE)
-      rc = describe_fuse(p, h->dtype, &ls[i]);
-    else
-      rc = describe_conv(p, h->dtype, o.ks, o.stride, &ls[i]);
+    switch (o.kind) {
+      case UDP_OP_STEM: rc = describe_stem(p, h->dtype, &ls[i]); break;
+      case UDP_OP_STEM7: rc = describe_stem7(p, h->dtype, &ls[i]); break;
+      case UDP_OP_FUSE: rc = describe_fuse(p, h->dtype, &ls[i]); break;
+      case UDP_OP_MAXPOOL: rc = describe_maxpool(p, h->dtype, &ls[i]); break;
+      case UDP_OP_BILINEAR: rc = describe_bilinear(p, h->dtype, &ls[i]); break;
+      default: rc = describe_conv(p, h->dtype, o.ks, o.stride, &ls[i]);
+    }
     if (rc) return rc;
   }
   return UDP_OK;
@@ -405,6 +430,12 @@ extern "C" int udp_conv2d_fused(const udp_conv_op* o, int dtype, int n, const vo
   p.CoutPad = o->cout_pad;
   p.relu = o->relu;
   p.flip_from = n;
+  p.in_pitch = o->in_pitch ? o->in_pitch : o->cin;
+  p.in_coff = o->in_coff;
+  p.out_pitch = o->out_pitch ? o->out_pitch : o->cout;
+  p.out_coff = o->out_coff;
+  p.res_pitch = o->res_pitch ? o->res_pitch : o->cout;
+  p.res_coff = o->res_coff;
   p.in = in;
   p.out = out;
   p.out_nchw_f32 = o->out_buf == UDP_BUF_OUTPUT;

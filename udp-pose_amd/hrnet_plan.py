@@ -227,6 +227,8 @@ class HRNetProgram:
         readers = {}
         for idx, op in enumerate(self._ops):
             if op["out"] is not None:
+                if op["out"].id in producer:
+                    readers.setdefault(op["out"].id, []).append(producer[op["out"].id])   # earlier slice writers
                 producer[op["out"].id] = idx
             for t in [op["inp"], op["res"]] + [u for u, _ in op["ups"]]:
                 if t is not None:
@@ -241,6 +243,9 @@ class HRNetProgram:
                 if t is not None and t.id in producer:
                     deps.add(producer[t.id])
             out = op["out"]
+            if out is not None and out.id in phys:
+                deps.add(producer[out.id])      # later slice of a concat buffer: ordered after its other writers
+                out = None
             if out is not None:
                 pool = free.get(out.elems, [])
                 pick = None
@@ -278,6 +283,8 @@ class HRNetProgram:
             o.in_buf = _lib.UDP_BUF_NONE if op["inp"] is None else self._phys[op["inp"].id]
             o.out_buf = _lib.UDP_BUF_OUTPUT if op["out"] is None else self._phys[op["out"].id]
             o.res_buf = _lib.UDP_BUF_NONE if op["res"] is None else self._phys[op["res"].id]
+            for f in ("in_coff", "in_pitch", "out_coff", "out_pitch", "res_coff", "res_pitch"):
+                setattr(o, f, op.get(f, 0))
             o.lane = op["lane"]
             o.n_wait = len(op["wait"])
             for k, d in enumerate(op["wait"]):
@@ -300,7 +307,7 @@ class HRNetProgram:
 
     def macs_per_image(self):
         return sum(op["ks"] ** 2 * op["cin"] * op["cout"] * op["hout"] * op["wout"]
-                   for op in self._ops if op["kind"] != _lib.UDP_OP_FUSE)
+                   for op in self._ops if op["kind"] in (_lib.UDP_OP_STEM, _lib.UDP_OP_CONV, _lib.UDP_OP_STEM7))
 
     def activation_elems_per_image(self):
         """Layer-wise algorithmic traffic: every op reads its inputs once and writes its output once."""

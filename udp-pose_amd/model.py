@@ -92,7 +92,7 @@ class PoseHighResolutionNetHip:
     def _compile(self, h, w):
         if self._sd is None:
             raise RuntimeError("load_state_dict() first")
-        prog = HRNetProgram(self._sd, self.extra, h, w, self.dtype)
+        prog = self._make_program(h, w)
         blob = torch.from_numpy(prog.weight_blob()).to(self.device)
         ops = prog.ops_array()
         bufs = (C.c_int64 * len(prog.buf_elems))(*prog.buf_elems)
@@ -102,6 +102,9 @@ class PoseHighResolutionNetHip:
                                                h, w, prog.out_channels, C.byref(handle)))
         self._compiled[(h, w)] = (handle, blob, prog)
         return self._compiled[(h, w)]
+
+    def _make_program(self, h, w):
+        return HRNetProgram(self._sd, self.extra, h, w, self.dtype)
 
     def program(self, h, w):
         if self.device is None:
@@ -173,6 +176,41 @@ class PoseHighResolutionNetHip:
         return self.raw_forward(x, flip_test=False)
 
     forward = __call__
+
+
+class RSN18Hip(PoseHighResolutionNetHip):
+    """RSN-18 (RSN/exps/RSN18.coco/network.py, STAGE_NUM = 1) inference through the same C ABI;
+    ``state_dict`` in the reference module's key format; returns ``outputs[-1][-1]`` ([N,C,H/4,W/4])."""
+
+    def __init__(self, out_channels=17, dtype="f32", chl_num=256):
+        self.out_channels = int(out_channels)
+        self.chl_num = chl_num
+        self.dtype = dtype
+        self.device = None
+        self.use_graph = True
+        self._sd = None
+        self._compiled = {}
+        self._ws = None
+        self._io = {}
+
+    def load_state_dict(self, state_dict, strict=True):
+        from .synth import rsn18_param_shapes
+        sd = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+        want = rsn18_param_shapes(self.out_channels, self.chl_num)
+        missing = [k for k in want if k not in sd and not k.endswith("num_batches_tracked")]
+        unexpected = [k for k in sd if k not in want]
+        if missing or (strict and unexpected):
+            raise RuntimeError("state_dict mismatch: missing %s unexpected %s" % (missing[:5], unexpected[:5]))
+        for k, shape in want.items():
+            if k in sd and tuple(sd[k].shape) != tuple(shape):
+                raise RuntimeError("size mismatch for %s: %s vs %s" % (k, tuple(sd[k].shape), tuple(shape)))
+        self._sd = sd
+        self._release()
+        return self
+
+    def _make_program(self, h, w):
+        from .rsn_plan import RSNProgram
+        return RSNProgram(self._sd, h, w, self.dtype, self.chl_num)
 
 
 def get_pose_net(cfg, is_train, **kwargs):

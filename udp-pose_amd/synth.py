@@ -257,3 +257,75 @@ def synth_heatmaps(n, j, h=64, w=48, seed=0, channels_per_joint=1):
                 out[a, 3 * b + 1] = (dx * disk).astype(np.float32) + noise[1]
                 out[a, 3 * b + 2] = (dy * disk).astype(np.float32) + noise[2]
     return out
+
+
+# ----------------------------------------------------------------------------
+# RSN-18 (RSN/exps/RSN18.coco/network.py): weight-file contract + synthetic weights
+# ----------------------------------------------------------------------------
+def _cbr(shapes, name, cin, cout, k):
+    shapes[name + ".conv.weight"] = (cout, cin, k, k)
+    shapes[name + ".conv.bias"] = (cout,)
+    shapes[name + ".bn.weight"] = (cout,)
+    shapes[name + ".bn.bias"] = (cout,)
+    shapes[name + ".bn.running_mean"] = (cout,)
+    shapes[name + ".bn.running_var"] = (cout,)
+    shapes[name + ".bn.num_batches_tracked"] = ()
+
+
+def rsn18_param_shapes(out_channels=17, chl_num=256):
+    """Ordered {key: shape} of RSN(cfg).state_dict() for STAGE_NUM=1, layers [2,2,2,2]
+    (network.py:343-396: top, stage0.downsample.layer1-4, stage0.upsample.up1-4)."""
+    s = OrderedDict()
+    _cbr(s, "top.conv", 3, 64, 7)
+    in_planes = 64
+    for layer, planes in zip(range(1, 5), (64, 128, 256, 512)):
+        for b in range(2):
+            p = "stage0.downsample.layer%d.%d" % (layer, b)
+            bch = in_planes * 26 // 64
+            _cbr(s, p + ".conv_bn_relu1", in_planes, 4 * bch, 1)
+            for nm in ("2_1_1", "2_2_1", "2_2_2", "2_3_1", "2_3_2", "2_3_3", "2_4_1", "2_4_2", "2_4_3", "2_4_4"):
+                _cbr(s, p + ".conv_bn_relu" + nm, bch, bch, 3)
+            _cbr(s, p + ".conv_bn_relu3", 4 * bch, planes, 1)
+            if b == 0 and (layer > 1 or in_planes != planes):
+                _cbr(s, p + ".downsample", in_planes, planes, 1)
+            in_planes = planes
+    for ind, cin in enumerate((512, 256, 128, 64)):
+        p = "stage0.upsample.up%d" % (ind + 1)
+        _cbr(s, p + ".u_skip", cin, chl_num, 1)
+        if ind > 0:
+            _cbr(s, p + ".up_conv", chl_num, chl_num, 1)
+        _cbr(s, p + ".res_conv1", chl_num, chl_num, 1)
+        _cbr(s, p + ".res_conv2", chl_num, out_channels, 3)
+    return s
+
+
+def synth_rsn18_state_dict(out_channels=17, seed=0, bn_calib=None):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    sd = OrderedDict()
+    for name, shape in rsn18_param_shapes(out_channels).items():
+        if name.endswith("num_batches_tracked"):
+            sd[name] = torch.tensor(0, dtype=torch.long)
+            continue
+        if name.endswith("running_mean"):
+            a = np.zeros(shape, np.float32)
+        elif name.endswith("running_var"):
+            a = np.ones(shape, np.float32)
+        elif len(shape) == 4:
+            a = rng.standard_normal(shape).astype(np.float32) * np.float32(np.sqrt(2.0 / (shape[1] * shape[2] * shape[3])))
+        elif name.endswith("conv.bias"):
+            a = (rng.standard_normal(shape) * 0.02).astype(np.float32)
+        elif name.endswith("bn.weight"):
+            closing = "conv_bn_relu3" in name or "downsample" in name or "up_conv" in name or "u_skip" in name
+            a = rng.uniform(0.2, 0.4, shape).astype(np.float32) if closing else rng.uniform(0.4, 0.8, shape).astype(np.float32)
+        else:
+            a = (rng.standard_normal(shape) * 0.05).astype(np.float32)
+        sd[name] = torch.from_numpy(a)
+    if bn_calib is not None:
+        for k, v in bn_calib.items():
+            if k in sd:
+                sd[k] = torch.from_numpy(np.asarray(v, dtype=np.float32).copy())
+        if "final.scale" in bn_calib:
+            f = float(np.asarray(bn_calib["final.scale"]))
+            for k in ("stage0.upsample.up4.res_conv2.bn.weight", "stage0.upsample.up4.res_conv2.bn.bias"):
+                sd[k] = sd[k] * f
+    return sd

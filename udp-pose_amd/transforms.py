@@ -34,8 +34,9 @@ def channel_map(num_channels, matched_parts, is_offset):
     return src, sign
 
 
-def flip_fuse(output, output_flipped, matched_parts, is_offset=False, out=None):
-    """(output + flip_back*(output_flipped)) * 0.5 on device; cuda fp32 [N,C,H,W]."""
+def flip_fuse(output, output_flipped, matched_parts, is_offset=False, out=None, divisor=1.0):
+    """(output + flip_back*(output_flipped)) * 0.5 [/ divisor] on device; cuda fp32 [N,C,H,W].
+    divisor=255 gives the RSN test loop's ``outputs/255.0`` (RSN .../test.py:181-185)."""
     if not (output.is_cuda and output_flipped.is_cuda):
         raise RuntimeError("udp-pose_amd has no CPU path: tensors must live on the GPU")
     assert output.dim() == 4, "output_flipped should be [batch_size, num_joints, height, width]"
@@ -47,8 +48,9 @@ def flip_fuse(output, output_flipped, matched_parts, is_offset=False, out=None):
     sign_t = torch.from_numpy(sign).to(output.device)
     if out is None:
         out = torch.empty_like(output)
-    _lib.check(_lib.lib().udp_flip_fuse(_lib.ptr(output), _lib.ptr(output_flipped), _lib.ptr(src_t),
-                                        _lib.ptr(sign_t), n, c, h, w, _lib.ptr(out), _lib.stream_ptr()))
+    _lib.check(_lib.lib().udp_flip_fuse_scaled(_lib.ptr(output), _lib.ptr(output_flipped), _lib.ptr(src_t),
+                                               _lib.ptr(sign_t), n, c, h, w, float(divisor), _lib.ptr(out),
+                                               _lib.stream_ptr()))
     return out
 
 
