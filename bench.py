@@ -39,11 +39,19 @@ PEAK_HBM_GBS = 8000.0
 
 
 # model -> (MODEL.EXTRA, input H, input W, weight seed); w32 = BASELINE.json configs[1], w48 = configs[3]
-MODELS_CFG = {"w32": (synth.W32_EXTRA, 256, 192, 0), "w48": (synth.scaled_extra(48), 384, 288, 2)}
+# rsn18 = configs[4]: RSN-18 backbone with the 51-channel offset head + UDP offset decode
+MODELS_CFG = {"w32": (synth.W32_EXTRA, 256, 192, 0), "w48": (synth.scaled_extra(48), 384, 288, 2),
+              "rsn18": (None, 256, 192, 4)}
 
 
 def build_net(dtype, target_type="gaussian", model="w32"):
     extra, _, _, seed = MODELS_CFG[model]
+    if model == "rsn18":
+        from udp_pose_amd.model import RSN18Hip
+        och = 51 if target_type == "offset" else 17
+        cp = os.path.join(ROOT, "tests", "golden", "bn_calib_rsn18_%d.npz" % och)
+        sd = synth.synth_rsn18_state_dict(och, seed=seed, bn_calib=dict(np.load(cp)) if os.path.exists(cp) else None)
+        return sd, RSN18Hip(och, dtype=dtype).load_state_dict(sd)
     calib_path = os.path.join(ROOT, "tests", "golden", "bn_calib_%s_%s.npz" % (model, target_type))
     calib = dict(np.load(calib_path)) if os.path.exists(calib_path) else None
     sd = synth.synth_state_dict(extra, 17, target_type, seed=seed, bn_calib=calib)
@@ -56,8 +64,10 @@ def build_net(dtype, target_type="gaussian", model="w32"):
 class HotPath:
     """forward(+mirrored) -> flip fuse -> decode, all on device, fixed buffers."""
 
-    def __init__(self, net, batch, device, seed, h=256, w=192):
+    def __init__(self, net, batch, device, seed, h=256, w=192, target_type="gaussian"):
         self.net, self.n, self.h, self.w = net.to(device), batch, h, w
+        self.tt = target_type
+        self.ch = 51 if target_type == "offset" else 17
         crops = synth.synth_crops(min(batch, 8), h, w, seed=seed)
         reps = (batch + crops.shape[0] - 1) // crops.shape[0]
         x = torch.from_numpy(np.tile(crops, (reps, 1, 1, 1))[:batch]).to(device)
@@ -67,17 +77,17 @@ class HotPath:
         c, s = synth.synth_center_scale(batch, seed=seed)
         self.center = torch.from_numpy(c.astype(np.float64)).to(device)
         self.scale = torch.from_numpy(s.astype(np.float64)).to(device)
-        src, sign = channel_map(17, COCO_FLIP_PAIRS, False)
+        src, sign = channel_map(self.ch, COCO_FLIP_PAIRS, target_type == "offset")
         self.src = torch.from_numpy(src).to(device)
         self.sign = torch.from_numpy(sign).to(device)
-        self.fused = torch.empty(batch, 17, h // 4, w // 4, device=device)
+        self.fused = torch.empty(batch, self.ch, h // 4, w // 4, device=device)
 
     def step(self):
         raw = self.net.raw_forward(self.xin, flip_test=True)
         n = self.n
         _lib.check(_lib.lib().udp_flip_fuse(_lib.ptr(raw), C_ptr(raw, n), _lib.ptr(self.src), _lib.ptr(self.sign),
-                                            n, 17, self.h // 4, self.w // 4, _lib.ptr(self.fused), _lib.stream_ptr()))
-        return decode_device(self.fused, self.center, self.scale, "gaussian", True, 4.0, True, want_idx=False)
+                                            n, self.ch, self.h // 4, self.w // 4, _lib.ptr(self.fused), _lib.stream_ptr()))
+        return decode_device(self.fused, self.center, self.scale, self.tt, self.tt == "gaussian", 4.0, True, want_idx=False)
 
 
 def C_ptr(t, row):
@@ -96,10 +106,11 @@ def roofline(net, hp, steps, dtype):
     b = 2 * hp.n
     classes = {}
     for t, (name, kind, ks, stride, cin, cout, ho, wo) in zip(ms, desc):
-        key = "stem" if kind == 0 else ("fuse_sum" if kind == 2 else "conv%dx%d_s%d_nb%d" % (ks, ks, stride, 4 if cout > 32 else 2))
-        flops = 0.0 if kind == 2 else 2.0 * ks * ks * cin * cout * ho * wo * b
+        key = {0: "stem", 2: "fuse_sum", 3: "stem7x7", 4: "maxpool", 5: "bilinear"}.get(
+            kind, "conv%dx%d_s%d_nb%d" % (ks, ks, stride, 4 if cout % 64 == 0 else 2))
+        flops = 2.0 * ks * ks * cin * cout * ho * wo * b if kind in (0, 1, 3) else 0.0
         hin, win = ho * stride, wo * stride
-        byts = (hin * win * cin * (4 if kind == 0 else esz) + ho * wo * cout * esz) * b
+        byts = (hin * win * cin * (4 if kind in (0, 3) else esz) + ho * wo * cout * esz) * b
         c = classes.setdefault(key, [0.0, 0.0, 0.0, 0])
         c[0] += float(t)
         c[1] += flops
@@ -173,7 +184,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=0, help="crops per GPU per step (default 64; 32 for w48)")
-    ap.add_argument("--model", default="w32", choices=sorted(MODELS_CFG), help="w32 256x192 (headline) or w48 384x288")
+    ap.add_argument("--model", default="w32", choices=sorted(MODELS_CFG), help="w32 256x192 (headline), w48 384x288, rsn18 256x192 + offset head/decode")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches on lane streams instead of hipGraph replay")
@@ -196,10 +207,11 @@ def main():
 
     extra, in_h, in_w, _ = MODELS_CFG[args.model]
     if args.batch <= 0:
-        args.batch = 64 if args.model == "w32" else 32
-    sd, net = build_net(args.dtype, model=args.model)
+        args.batch = 32 if args.model == "w48" else 64
+    tt = "offset" if args.model == "rsn18" else "gaussian"
+    sd, net = build_net(args.dtype, target_type=tt, model=args.model)
     net.use_graph = not args.no_graph
-    hp = HotPath(net, args.batch, device, seed=100 + rank, h=in_h, w=in_w)
+    hp = HotPath(net, args.batch, device, seed=100 + rank, h=in_h, w=in_w, target_type=tt)
 
     def barrier():
         if dist is not None:
@@ -222,15 +234,15 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * args.batch * args.steps / dt
 
-    metric = "images/sec HRNet-W32 256x192 (infer+decode)" if args.model == "w32" else \
-        "images/sec HRNet-W48 384x288 (infer+decode)"
+    metric = {"w32": "images/sec HRNet-W32 256x192 (infer+decode)", "w48": "images/sec HRNet-W48 384x288 (infer+decode)",
+              "rsn18": "images/sec RSN-18 256x192 + UDP offset decode (infer+decode)"}[args.model]
     line = {"metric": metric, "value": round(value, 1), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": "pose_hrnet_%s %dx%d %s inference, batch=%d per GPU, flip-test on, DARK decode "
-                                   "(forward on 2N images + flip fuse + udp_decode_gaussian)" %
-                                   (args.model, in_h, in_w, args.dtype, args.batch),
+            "config": {"workload": "%s %dx%d %s inference, batch=%d per GPU, flip-test on, %s decode "
+                                   "(forward on 2N images + flip fuse + udp_decode_%s)" %
+                                   (args.model, in_h, in_w, args.dtype, args.batch, "DARK" if tt == "gaussian" else "offset", tt),
                        "global_batch": world * args.batch, "parallelism": "replicas x%d (no data-path collective)" % world,
                        "weights": "seeded synthetic, BN stats calibrated (tests/golden/bn_calib_%s_gaussian.npz)" % args.model}}
     if rank == 0:
