@@ -181,6 +181,51 @@ __device__ __forceinline__ void store_vec_buf(__amdgpu_buffer_rsrc_t r, unsigned
   }
 }
 
+// One chunk of MFMA work for a wave: all taps x k-steps of its MBW pixel blocks x NB cout blocks.
+// Software-pipelined by hand: the fragments of step s+1 are read from LDS before the MFMAs of step s
+// are issued, so LDS latency hides behind matrix work even at one or two waves per SIMD (hipcc does not
+// hoist the reads across the unrolled taps by itself).
+template <typename T, int KS, int NB, int MBW>
+__device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[MBW][NB], const unsigned char* sb, const unsigned char* wrow,
+                                           const int (&prow)[MBW], int IW, int kg, int wswz) {
+  constexpr bool F32 = std::is_same<T, float>::value;
+  constexpr int BN = NB * 16;
+  constexpr int NSTEP = KS * KS * (F32 ? 2 : 1);
+  using Frag = typename std::conditional<F32, f32x2, bf16x8>::type;
+  Frag wf[2][NB], pf[2][MBW];
+  auto load = [&](int s, Frag (&w)[NB], Frag (&x)[MBW]) {
+    const int tap = F32 ? s >> 1 : s;
+    const int ks = F32 ? (s & 1) : 0;
+    const int part = F32 ? 2 * ks + (kg >> 1) : kg;
+    const int sub = F32 ? (kg & 1) * 8 : 0;
+    const int tap_rows = (tap / KS) * IW + tap % KS;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+      w[nb] = *reinterpret_cast<const Frag*>(wrow + (tap * BN + nb * 16) * ROWB + ((part ^ wswz) << 4) + sub);
+#pragma unroll
+    for (int i = 0; i < MBW; ++i) {
+      const int row = prow[i] + tap_rows;
+      x[i] = *reinterpret_cast<const Frag*>(sb + row * ROWB + ((part ^ swz(row)) << 4) + sub);
+    }
+  };
+  load(0, wf[0], pf[0]);
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) {
+    if (s + 1 < NSTEP) load(s + 1, wf[(s + 1) & 1], pf[(s + 1) & 1]);
+#pragma unroll
+    for (int i = 0; i < MBW; ++i)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        if constexpr (F32) {
+          acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s & 1][nb][0], pf[s & 1][i][0], acc[i][nb], 0, 0, 0);
+          acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s & 1][nb][1], pf[s & 1][i][1], acc[i][nb], 0, 0, 0);
+        } else {
+          acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s & 1][nb], pf[s & 1][i], acc[i][nb], 0, 0, 0);
+        }
+      }
+  }
+}
+
 // MBW = 16-pixel blocks per wave (ceil(M/64)); NCHW = epilogue writes the fp32 NCHW network output.
 template <typename T, int KS, int STRIDE, int NB, int MBW, bool NCHW>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
@@ -323,45 +368,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     if (c == 0) UDP_STAMP(4);
     if (c + 1 < nchunks) stage(c + 1, smem + ((c + 1) & 1) * stage_bytes);
     const unsigned char* sb = smem + (c & 1) * stage_bytes;
-    const unsigned char* wb = sb + in_bytes + li * ROWB;
-#pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-      const int ky = tap / KS, kx = tap % KS;
-      const int tap_rows = ky * IW + kx;
-      if constexpr (std::is_same<T, float>::value) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const int part = 2 * ks + (kg >> 1), sub = (kg & 1) * 8;
-          f32x2 wf[NB];
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb)
-            wf[nb] = *reinterpret_cast<const f32x2*>(wb + (tap * BN + nb * 16) * ROWB + ((part ^ wswz) << 4) + sub);
-#pragma unroll
-          for (int i = 0; i < MBW; ++i) {
-            const int row = prow[i] + tap_rows;
-            const f32x2 pf = *reinterpret_cast<const f32x2*>(sb + row * ROWB + ((part ^ swz(row)) << 4) + sub);
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-              acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nb][0], pf[0], acc[i][nb], 0, 0, 0);
-              acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nb][1], pf[1], acc[i][nb], 0, 0, 0);
-            }
-          }
-        }
-      } else {
-        bf16x8 wf[NB];
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-          wf[nb] = *reinterpret_cast<const bf16x8*>(wb + (tap * BN + nb * 16) * ROWB + ((kg ^ wswz) << 4));
-#pragma unroll
-        for (int i = 0; i < MBW; ++i) {
-          const int row = prow[i] + tap_rows;
-          const bf16x8 pf = *reinterpret_cast<const bf16x8*>(sb + row * ROWB + ((kg ^ swz(row)) << 4));
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb)
-            acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb], pf, acc[i][nb], 0, 0, 0);
-        }
-      }
-    }
+    mfma_chunk<T, KS, NB, MBW>(acc, sb, sb + in_bytes + li * ROWB, prow, IW, kg, wswz);
   }
 
   UDP_STAMP(5);
@@ -544,7 +551,6 @@ __global__ __launch_bounds__(256) void conv_mfma_persist1(const ConvParams p) {
   stage_in(t, in_lds);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-  const unsigned char* wb = w_lds + li * ROWB + (std::is_same<T, float>::value ? 0 : ((kg ^ wswz) << 4));
   for (int it = 0; t < ntiles; t += gridDim.x, ++it) {
     // every wave has waited for its own DMA of this tile; after the barrier all of it is visible and
     // nobody still reads the other buffer
@@ -557,43 +563,7 @@ __global__ __launch_bounds__(256) void conv_mfma_persist1(const ConvParams p) {
     for (int i = 0; i < MBW; ++i)
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) acc[i][nb] = bias[nb];
-#pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-      const int ky = tap / KS, kx = tap % KS;
-      const int tap_rows = ky * IW + kx;
-      if constexpr (std::is_same<T, float>::value) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const int part = 2 * ks + (kg >> 1), sub = (kg & 1) * 8;
-          f32x2 wf[NB];
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb)
-            wf[nb] = *reinterpret_cast<const f32x2*>(wb + (tap * BN + nb * 16) * ROWB + ((part ^ wswz) << 4) + sub);
-#pragma unroll
-          for (int i = 0; i < MBW; ++i) {
-            const int row = prow[i] + tap_rows;
-            const f32x2 pf = *reinterpret_cast<const f32x2*>(sb + row * ROWB + ((part ^ swz(row)) << 4) + sub);
-#pragma unroll
-            for (int nb = 0; nb < NB; ++nb) {
-              acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nb][0], pf[0], acc[i][nb], 0, 0, 0);
-              acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[nb][1], pf[1], acc[i][nb], 0, 0, 0);
-            }
-          }
-        }
-      } else {
-        bf16x8 wf[NB];
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) wf[nb] = *reinterpret_cast<const bf16x8*>(wb + (tap * BN + nb * 16) * ROWB);
-#pragma unroll
-        for (int i = 0; i < MBW; ++i) {
-          const int row = prow[i] + tap_rows;
-          const bf16x8 pf = *reinterpret_cast<const bf16x8*>(sb + row * ROWB + ((kg ^ swz(row)) << 4));
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb)
-            acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb], pf, acc[i][nb], 0, 0, 0);
-        }
-      }
-    }
+    mfma_chunk<T, KS, NB, MBW>(acc, sb, w_lds + li * ROWB, prow, IW, kg, wswz);
 
     // ---- epilogue of tile t
     int n0, y0, x0;
