@@ -821,7 +821,12 @@ static int largest_divisor_leq(int n, int lim) {
 
 // Picks the (G, R, TW) tile and NB for one conv; returns the dynamic LDS bytes.
 size_t conv_choose_tile(ConvParams& p, int ks, int stride, int dtype, int* nb_out) {
-  const int kMaxM = 256;
+  // tuning knobs (environment overrides are a measurement aid for tools/profile_layers.py)
+  auto knob = [](const char* name, long dflt) {
+    const char* v = getenv(name);
+    return v ? atol(v) : dflt;
+  };
+  const int kMaxM = (int)knob("UDP_POSE_MAXM", 256);
   const int ck = dtype == UDP_F32 ? 16 : 32;
   const int nstage = ceil_div(p.Cin, ck) > 1 ? 2 : 1;
   int TW = p.Wout;
@@ -846,10 +851,10 @@ size_t conv_choose_tile(ConvParams& p, int ks, int stride, int dtype, int* nb_ou
     return (long)ceil_div(p.N, g) * ceil_div(p.Hout, r) * ceil_div(p.Wout, TW) * (p.CoutPad / (nb * 16));
   };
   // small problems: trade tile size for workgroups (256 CUs, aim for >= 2 per CU)
-  const long kMinWgs = 512;
+  const long kMinWgs = knob("UDP_POSE_MINWGS", 512);
   if (wgs(G, R, NB) < kMinWgs && NB == 4) NB = 2;
   while (wgs(G, R, NB) < kMinWgs && G > 1) G = (G + 1) / 2;
-  const size_t kLimit = 76 * 1024;   // two workgroups per CU
+  const size_t kLimit = (size_t)knob("UDP_POSE_LDS_KB", 76) * 1024;   // 76 KB: two workgroups per CU
   while ((lds(G, R, NB) > kLimit || npix(G, R) > MAXG * 64) && G > 1) --G;
   while ((lds(G, R, NB) > kLimit || npix(G, R) > MAXG * 64) && NB == 4) NB = 2;
   while ((lds(G, R, NB) > kLimit || npix(G, R) > MAXG * 64) && R > 1) R = (R + 1) / 2;
