@@ -63,7 +63,14 @@ enum udp_op_kind {
   UDP_OP_FUSE = 2, /* no conv: out = act(in [+ res] + sum_k nearest_up(up_k))  */
   UDP_OP_STEM7 = 3,   /* 7x7 s2 p3 conv, Cin=3, reads the NCHW fp32 network input (RSN top) */
   UDP_OP_MAXPOOL = 4, /* MaxPool2d(3, stride 2, pad 1) */
-  UDP_OP_BILINEAR = 5 /* bilinear resize, align_corners=True, hin x win -> hout x wout */
+  UDP_OP_BILINEAR = 5, /* bilinear resize, align_corners=True, hin x win -> hout x wout */
+  /* Polarized self-attention PSA_s (deep_hrnet/lib/models/PSA.py:190-269) of pose_hrnet_psa, per image;
+   * w_off = fp32 block wq[C] | Wv[C/2][C] | W1[C/8][C/2] | b1 | ln_g | ln_b | W2[C][C/8] | b2[C] | Wg[C/2][C] */
+  UDP_OP_PSA_POOL = 6,  /* in = x [C];   out = fp32 {sum_p softmax(wq.x)_p x_p, mean_p x_p}  (2C floats) */
+  UDP_OP_PSA_MLP = 7,   /* in = POOL out; out = fp32 {channel mask m[C], gbar[C/2]}            (3C/2 floats) */
+  UDP_OP_PSA_SCALE = 8, /* in = x, res = MLP out; out = x * m[c] */
+  UDP_OP_PSA_SP = 9     /* in = theta [C/2] (1x1 conv of the scaled map), res = scaled map [C], up_buf[0] = MLP out;
+                           out = res * sigmoid(sum_j gbar_j softmax_HW(theta_j)) */
 };
 
 #define UDP_MAX_LANES 4

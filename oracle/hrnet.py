@@ -45,8 +45,30 @@ class _Net:
         return (name + ".weight") in self.sd
 
 
+def _psa_s(net, x, p):
+    """PSA_s.forward (deep_hrnet/lib/models/PSA.py:190-269): spatial_pool then channel_pool."""
+    sd = net.sd
+    n, c, h, w = x.shape
+    # spatial_pool :190-222
+    v = F.conv2d(x, sd[p + ".conv_v_right.weight"]).view(n, c // 2, h * w)
+    q = F.softmax(F.conv2d(x, sd[p + ".conv_q_right.weight"]).view(n, 1, h * w), dim=2)
+    ctx = torch.matmul(v, q.transpose(1, 2)).unsqueeze(-1)                           # [N, C/2, 1, 1]
+    ctx = F.conv2d(ctx, sd[p + ".conv_up.0.weight"], sd[p + ".conv_up.0.bias"])
+    ctx = F.layer_norm(ctx, [c // 8, 1, 1], sd[p + ".conv_up.1.weight"], sd[p + ".conv_up.1.bias"], 1e-5)
+    ctx = F.conv2d(F.relu(ctx), sd[p + ".conv_up.3.weight"], sd[p + ".conv_up.3.bias"])
+    out = x * torch.sigmoid(ctx)
+    # channel_pool :224-258
+    g = F.conv2d(out, sd[p + ".conv_q_left.weight"])
+    avg = F.adaptive_avg_pool2d(g, 1).view(n, c // 2, 1).permute(0, 2, 1)             # [N, 1, C/2]
+    theta = F.softmax(F.conv2d(out, sd[p + ".conv_v_left.weight"]).view(n, c // 2, h * w), dim=2)
+    ctx = torch.matmul(avg, theta).view(n, 1, h, w)
+    return out * torch.sigmoid(ctx)
+
+
 def _basic_block(net, x, p):
     out = F.relu(net.bn(net.conv(x, p + ".conv1"), p + ".bn1"))
+    if (p + ".deattn.conv_q_right.weight") in net.sd:            # pose_hrnet_psa.py:49
+        out = _psa_s(net, out, p + ".deattn")
     out = net.bn(net.conv(out, p + ".conv2"), p + ".bn2")
     return F.relu(out + x)
 

@@ -49,6 +49,28 @@ def test_mini_hrnet_matches_reference_fixture(golden_dir):
     np.testing.assert_array_equal(got.reshape(2, 5, -1).argmax(2), g["out"].reshape(2, 5, -1).argmax(2))
 
 
+def test_psa_mini_matches_reference_fixture(golden_dir):
+    """pose_hrnet_psa mini net (PSA.py:190-269 after conv1 of every BasicBlock) vs the REFERENCE module."""
+    g = np.load(os.path.join(golden_dir, "hrnet_psa_mini.npz"))
+    extra = synth.scaled_extra(32, modules=(1, 2, 1), blocks=2)
+    calib = {k[len("calib_"):]: g[k] for k in g.files if k.startswith("calib_")}
+    sd = synth.synth_state_dict(extra, 17, "gaussian", seed=6, bn_calib=calib, psa=True)
+    x = torch.from_numpy(synth.synth_crops(2, 128, 96, seed=24)).cuda()
+    net = MODELS["pose_hrnet_psa"](_cfg(extra, 17, "gaussian"), is_train=False).load_state_dict(sd).to("cuda")
+    got = net(x).clone().cpu().numpy()
+    assert got.shape == (2, 17, 32, 24)
+    np.testing.assert_allclose(got, g["out"], rtol=0, atol=1e-3)
+    np.testing.assert_array_equal(got.reshape(2, 17, -1).argmax(2), g["out"].reshape(2, 17, -1).argmax(2))
+    # flip-folded batch (images N..2N-1 mirrored) still matches a separate mirrored forward
+    both = net.raw_forward(x, flip_test=True).clone()
+    mirrored = net(torch.flip(x, dims=[3])).clone()
+    torch.testing.assert_close(both[2:], mirrored, rtol=0, atol=1e-5)
+    # bf16 storage: sanity only (attention softmax amplifies rounding; gate = fraction of the signal)
+    nb = MODELS["pose_hrnet_psa"](_cfg(extra, 17, "gaussian"), is_train=False, dtype="bf16").load_state_dict(sd).to("cuda")
+    gb = nb(x).clone().cpu().numpy()
+    assert np.sqrt(((gb - g["out"]) ** 2).mean()) < 0.15 * g["out"].std()
+
+
 @pytest.mark.parametrize("modules,blocks", [((1, 1, 1), 1), ((1, 2, 2), 2)])
 def test_small_hrnet_fp32_all_module_kinds(modules, blocks):
     extra = synth.scaled_extra(32, modules=modules, blocks=blocks)

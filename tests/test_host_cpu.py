@@ -123,3 +123,25 @@ def test_lanes_order_every_buffer_hazard():
             touched.setdefault(b, []).append((i, "r"))
         for b in writes:
             touched.setdefault(b, []).append((i, "w"))
+
+
+def test_psa_program_emission():
+    """pose_hrnet_psa: five ops per BasicBlock (pool, mlp, scale, theta conv, sp) between conv1 and conv2."""
+    extra = synth.scaled_extra(32, modules=(1, 2, 1), blocks=2)
+    sd = synth.synth_state_dict(extra, 17, "gaussian", seed=6, psa=True)
+    prog = hrnet_plan.HRNetProgram(sd, extra, 128, 96, "bf16")
+    plain = hrnet_plan.HRNetProgram({k: v for k, v in sd.items() if ".deattn." not in k}, extra, 128, 96, "bf16")
+    n_blocks = sum(1 for k in sd if k.endswith(".deattn.conv_q_right.weight"))
+    assert n_blocks == 2 * (2 * 1 + 3 * 2 + 4 * 1)
+    assert len(prog.describe()) == len(plain.describe()) + 5 * n_blocks
+    kinds = [d[1] for d in prog.describe()]
+    for k in (_lib.UDP_OP_PSA_POOL, _lib.UDP_OP_PSA_MLP, _lib.UDP_OP_PSA_SCALE, _lib.UDP_OP_PSA_SP):
+        assert kinds.count(k) == n_blocks
+    arr = prog.ops_array()
+    for i, d in enumerate(prog.describe()):
+        if d[1] == _lib.UDP_OP_PSA_SP:
+            assert arr[i].n_up == 1 and arr[i].cin * 2 == arr[i].cout
+            assert arr[i - 1].kind == _lib.UDP_OP_CONV and arr[i - 1].cout == arr[i].cin      # theta
+    with pytest.raises(ValueError):
+        sd48 = synth.synth_state_dict(synth.scaled_extra(48, modules=(1, 1, 1), blocks=1), 17, "gaussian", seed=6, psa=True)
+        hrnet_plan.HRNetProgram(sd48, synth.scaled_extra(48, modules=(1, 1, 1), blocks=1), 128, 96, "bf16")

@@ -165,6 +165,27 @@ def test_mini_hrnet_matches_reference(golden_dir):
     assert g["tap_stage4.0"].shape[1] == 4 * 16                  # last fuse widens to 4C
 
 
+def _psa_mini(golden_dir):
+    g = _g(golden_dir, "hrnet_psa_mini.npz")
+    extra = synth.scaled_extra(32, modules=(1, 2, 1), blocks=2)
+    calib = {k[len("calib_"):]: g[k] for k in g.files if k.startswith("calib_")}
+    sd = synth.synth_state_dict(extra, 17, "gaussian", seed=6, bn_calib=calib, psa=True)
+    return g, extra, sd
+
+
+def test_psa_mini_matches_reference(golden_dir):
+    """pose_hrnet_psa (PSA_s after conv1 of every BasicBlock): reference module heat-maps + key contract."""
+    g, extra, sd = _psa_mini(golden_dir)
+    x = torch.from_numpy(synth.synth_crops(2, 128, 96, seed=24))
+    y = ohrnet.hrnet_forward(sd, extra, x).numpy()
+    np.testing.assert_allclose(y, g["out"], rtol=0, atol=1e-5)
+    ours = sorted("%s:%s" % (k, "x".join(map(str, v))) for k, v in synth.hrnet_param_shapes(extra, 17, "gaussian", psa=True).items())
+    assert ours == [str(k) for k in g["keys"]]
+    # the attention is not a no-op on these weights
+    plain = {k: v for k, v in sd.items() if ".deattn." not in k}
+    assert np.abs(ohrnet.hrnet_forward(plain, extra, x).numpy() - y).max() > 1e-2
+
+
 def test_w32_matches_reference(golden_dir):
     g = _g(golden_dir, "hrnet_w32_gaussian.npz")
     calib = dict(_g(golden_dir, "bn_calib_w32_gaussian.npz"))

@@ -14,6 +14,7 @@ int describe_fuse(const ConvParams& p, int dtype, Launch* out);
 int describe_stem7(const ConvParams& p, int dtype, Launch* out);
 int describe_maxpool(const ConvParams& p, int dtype, Launch* out);
 int describe_bilinear(const ConvParams& p, int dtype, Launch* out);
+int describe_psa(const ConvParams& p, int dtype, int kind, Launch* out);
 int run_launch(const Launch& l, hipStream_t s);
 }  // namespace udp
 
@@ -53,7 +54,29 @@ static int validate_op(const udp_hrnet* h, const udp_conv_op& o, int idx) {
   const int nb = (int)h->buf_elems.size();
   auto buf_ok = [&](int b, int64_t need) { return b >= 0 && b < nb && h->buf_elems[b] >= need; };
   const int64_t out_need = (int64_t)o.hout * o.wout * (o.out_pitch ? o.out_pitch : o.cout);
-  if (o.kind < UDP_OP_STEM || o.kind > UDP_OP_BILINEAR) return fail(UDP_ERR_ARG, "op %d: bad kind %d", idx, o.kind);
+  if (o.kind < UDP_OP_STEM || o.kind > UDP_OP_PSA_SP) return fail(UDP_ERR_ARG, "op %d: bad kind %d", idx, o.kind);
+  if (o.lane < 0 || o.lane >= UDP_MAX_LANES || o.n_wait < 0 || o.n_wait > UDP_MAX_WAIT) return fail(UDP_ERR_ARG, "op %d: lane/n_wait", idx);
+  for (int k = 0; k < o.n_wait; ++k)
+    if (o.wait_op[k] < 0 || o.wait_op[k] >= idx) return fail(UDP_ERR_ARG, "op %d: wait_op %d must name an earlier op", idx, o.wait_op[k]);
+  if (o.kind >= UDP_OP_PSA_POOL) {
+    // polarized self-attention ops: per-image side buffers hold fp32 rows, counted in `dtype` elements
+    const int64_t f = 4 / (int64_t)esize(h->dtype);
+    const int64_t hw = (int64_t)o.hin * o.win;
+    const int C = o.kind == UDP_OP_PSA_SP ? o.cout : o.cin;
+    if (C <= 0 || hw <= 0 || C % 16) return fail(UDP_ERR_ARG, "op %d: PSA shape", idx);
+    const size_t wbytes = (size_t)(C + (C / 2) * C + (C / 8) * (C / 2) + 3 * (C / 8) + C * (C / 8) + C + (C / 2) * C) * 4;
+    bool ok = true;
+    switch (o.kind) {
+      case UDP_OP_PSA_POOL: ok = buf_ok(o.in_buf, hw * C) && buf_ok(o.out_buf, 2 * C * f); break;
+      case UDP_OP_PSA_MLP: ok = buf_ok(o.in_buf, 2 * C * f) && buf_ok(o.out_buf, (C + C / 2) * f); break;
+      case UDP_OP_PSA_SCALE: ok = buf_ok(o.in_buf, hw * C) && buf_ok(o.res_buf, (C + C / 2) * f) && buf_ok(o.out_buf, hw * C); break;
+      default: ok = buf_ok(o.in_buf, hw * (C / 2)) && buf_ok(o.res_buf, hw * C) && o.n_up == 1 && buf_ok(o.up_buf[0], (C + C / 2) * f) && buf_ok(o.out_buf, hw * C);
+    }
+    if (!ok) return fail(UDP_ERR_ARG, "op %d: PSA buffers missing or too small", idx);
+    if (o.kind <= UDP_OP_PSA_MLP && (o.w_off < 0 || (size_t)o.w_off + wbytes > h->weights_bytes || (o.w_off & 15)))
+      return fail(UDP_ERR_ARG, "op %d: PSA parameter block outside the blob or misaligned", idx);
+    return UDP_OK;
+  }
   const bool is_stem = o.kind == UDP_OP_STEM || o.kind == UDP_OP_STEM7;
   const bool has_w = is_stem || o.kind == UDP_OP_CONV;
   const int ipitch = o.in_pitch ? o.in_pitch : o.cin, opitch = o.out_pitch ? o.out_pitch : o.cout;
@@ -228,8 +251,16 @@ static int describe_all(const udp_hrnet* h, const float* in, int n, int flip, ch
       p.wgt = h->weights + o.w_off;
       p.bias = reinterpret_cast<const float*>(h->weights + o.b_off);
     }
+    if (o.kind >= UDP_OP_PSA_POOL) {
+      p.wgt = h->weights + o.w_off;
+      if (o.kind == UDP_OP_PSA_SCALE) p.res_pitch = o.cin + o.cin / 2;   // fp32 rows {m[C], gbar[C/2]}
+    }
     int rc;
     switch (o.kind) {
+      case UDP_OP_PSA_POOL:
+      case UDP_OP_PSA_MLP:
+      case UDP_OP_PSA_SCALE:
+      case UDP_OP_PSA_SP: rc = describe_psa(p, h->dtype, o.kind, &ls[i]); break;
       case UDP_OP_STEM: rc = describe_stem(p, h->dtype, &ls[i]); break;
       case UDP_OP_STEM7: rc = describe_stem7(p, h->dtype, &ls[i]); break;
       case UDP_OP_FUSE: rc = describe_fuse(p, h->dtype, &ls[i]); break;

@@ -115,6 +115,35 @@ class HRNetProgram:
                               ups=list(ups), w_off=w_off, b_off=b_off, name=conv))
         return out
 
+    def _psa(self, x, p):
+        """PSA_s (PSA.py:190-269) as POOL -> MLP -> SCALE -> 1x1 conv (theta) -> SP; see csrc/psa.hip."""
+        sd, C = self.sd, x.c
+        if 256 % C or C % 16:
+            raise ValueError("%s: PSA needs a channel count that divides 256 (got %d)" % (p, C))
+        f32 = lambda k: sd[p + k].detach().to(torch.float32).cpu().reshape(-1)
+        block = torch.cat([f32(".conv_q_right.weight"), f32(".conv_v_right.weight"), f32(".conv_up.0.weight"),
+                           f32(".conv_up.0.bias"), f32(".conv_up.1.weight"), f32(".conv_up.1.bias"),
+                           f32(".conv_up.3.weight"), f32(".conv_up.3.bias"), f32(".conv_q_left.weight")])
+        want = C + C // 2 * C + C // 8 * (C // 2) + 3 * (C // 8) + C * (C // 8) + C + C // 2 * C
+        if block.numel() != want:
+            raise ValueError("%s: PSA parameter shapes do not match planes=%d" % (p, C))
+        w_off = self._put(block.numpy().tobytes())
+        f = 4 // (2 if self.dtype == "bf16" else 4)                      # fp32 side rows, counted in dtype elements
+        base = dict(ks=1, stride=1, relu=0, cout_pad=_round_up(C, 32), hin=x.h, win=x.w, hout=x.h, wout=x.w,
+                    res=None, ups=[], w_off=w_off, b_off=0)
+        pooled = self._new(2 * C * f, 1, 1)
+        self._ops.append(dict(base, kind=_lib.UDP_OP_PSA_POOL, cin=C, cout=C, inp=x, out=pooled, name=p + ".pool"))
+        mask = self._new((C + C // 2) * f, 1, 1)
+        self._ops.append(dict(base, kind=_lib.UDP_OP_PSA_MLP, cin=C, cout=C, inp=pooled, out=mask, name=p + ".mlp"))
+        x1 = self._new(C, x.h, x.w)
+        self._ops.append(dict(base, kind=_lib.UDP_OP_PSA_SCALE, cin=C, cout=C, inp=x, res=mask, out=x1,
+                              name=p + ".scale"))
+        theta = self._conv(x1, p + ".conv_v_left", None, relu=False)
+        x2 = self._new(C, x.h, x.w)
+        self._ops.append(dict(base, kind=_lib.UDP_OP_PSA_SP, cin=C // 2, cout=C, inp=theta, res=x1, ups=[(mask, 0)],
+                              out=x2, name=p + ".sp"))
+        return x2
+
     def _build(self):
         sd = self.sd
         H, W = self.in_h, self.in_w
@@ -176,6 +205,8 @@ class HRNetProgram:
             for k in range(num_blocks[b]):
                 q = "%s.branches.%d.%d" % (p, b, k)
                 t = self._conv(xs[b], q + ".conv1", q + ".bn1")
+                if (q + ".deattn.conv_q_right.weight") in self.sd:       # pose_hrnet_psa.py:37,49
+                    t = self._psa(t, q + ".deattn")
                 xs[b] = self._conv(t, q + ".conv2", q + ".bn2", res=xs[b])
         n_out = 1 if last else nb
         outs = []

@@ -26,7 +26,8 @@ def _get(cfg, *path):
 class PoseHighResolutionNetHip:
     """HRNet (UDP variant) inference on MI355X through the C ABI."""
 
-    def __init__(self, cfg, dtype="f32"):
+    def __init__(self, cfg, dtype="f32", psa=False):
+        self.psa = bool(psa)
         self.extra = _get(cfg, "MODEL", "EXTRA")
         self.num_joints = int(_get(cfg, "MODEL", "NUM_JOINTS"))
         self.target_type = _get(cfg, "MODEL", "TARGET_TYPE")
@@ -43,7 +44,7 @@ class PoseHighResolutionNetHip:
     # ---- nn.Module-like surface used by the reference's callers
     def load_state_dict(self, state_dict, strict=True):
         sd = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
-        want = hrnet_param_shapes(self.extra, self.num_joints, self.target_type)
+        want = hrnet_param_shapes(self.extra, self.num_joints, self.target_type, psa=self.psa)
         missing = [k for k in want if k not in sd and not k.endswith("num_batches_tracked")]
         unexpected = [k for k in sd if k not in want]
         if strict and (missing or unexpected):
@@ -220,4 +221,10 @@ def get_pose_net(cfg, is_train, **kwargs):
     return PoseHighResolutionNetHip(cfg, **kwargs)
 
 
-MODELS = {"pose_hrnet": get_pose_net}
+def get_pose_net_psa(cfg, is_train, **kwargs):
+    """pose_hrnet_psa.py get_pose_net: same plan, every BasicBlock carries "<block>.deattn.*" (PSA_s)
+    parameters and the planner emits the attention ops for them."""
+    return get_pose_net(cfg, is_train, psa=True, **kwargs)
+
+
+MODELS = {"pose_hrnet": get_pose_net, "pose_hrnet_psa": get_pose_net_psa}

@@ -25,8 +25,23 @@ def _bn(shapes, name, c):
     shapes[name + ".num_batches_tracked"] = ()
 
 
-def hrnet_param_shapes(extra, num_joints=17, target_type="gaussian"):
-    """Ordered {key: shape} of the reference PoseHighResolutionNet state_dict."""
+def _psa_s(shapes, name, c):
+    """PSA_s(planes, planes) parameters (deep_hrnet/lib/models/PSA.py:146-180) in registration order."""
+    shapes[name + ".conv_q_right.weight"] = (1, c, 1, 1)
+    shapes[name + ".conv_v_right.weight"] = (c // 2, c, 1, 1)
+    shapes[name + ".conv_up.0.weight"] = (c // 8, c // 2, 1, 1)
+    shapes[name + ".conv_up.0.bias"] = (c // 8,)
+    shapes[name + ".conv_up.1.weight"] = (c // 8, 1, 1)       # LayerNorm([C/8,1,1])
+    shapes[name + ".conv_up.1.bias"] = (c // 8, 1, 1)
+    shapes[name + ".conv_up.3.weight"] = (c, c // 8, 1, 1)
+    shapes[name + ".conv_up.3.bias"] = (c,)
+    shapes[name + ".conv_q_left.weight"] = (c // 2, c, 1, 1)
+    shapes[name + ".conv_v_left.weight"] = (c // 2, c, 1, 1)
+
+
+def hrnet_param_shapes(extra, num_joints=17, target_type="gaussian", psa=False):
+    """Ordered {key: shape} of the reference PoseHighResolutionNet state_dict (``psa``: the
+    pose_hrnet_psa variant, a PSA_s after bn1 of every BasicBlock, pose_hrnet_psa.py:37,49)."""
     s = OrderedDict()
     s["conv1.weight"] = (64, 3, 3, 3)
     _bn(s, "bn1", 64)
@@ -75,6 +90,8 @@ def hrnet_param_shapes(extra, num_joints=17, target_type="gaussian"):
                     q = "%s.branches.%d.%d" % (p, b, k)
                     s[q + ".conv1.weight"] = (chans[b], chans[b], 3, 3)
                     _bn(s, q + ".bn1", chans[b])
+                    if psa:
+                        _psa_s(s, q + ".deattn", chans[b])
                     s[q + ".conv2.weight"] = (chans[b], chans[b], 3, 3)
                     _bn(s, q + ".bn2", chans[b])
             inch = list(chans)
@@ -104,7 +121,7 @@ def hrnet_param_shapes(extra, num_joints=17, target_type="gaussian"):
     return s
 
 
-def synth_state_dict(extra, num_joints=17, target_type="gaussian", seed=0, bn_calib=None):
+def synth_state_dict(extra, num_joints=17, target_type="gaussian", seed=0, bn_calib=None, psa=False):
     """Seeded synthetic state_dict (fp32 torch tensors, CPU).
 
     conv ~ N(0, 2/fan_in); BN gamma ~ U(0.6,1.2) (0.25..0.5 for the closing BN of
@@ -114,7 +131,7 @@ def synth_state_dict(extra, num_joints=17, target_type="gaussian", seed=0, bn_ca
     """
     rng = np.random.Generator(np.random.PCG64(seed))
     sd = OrderedDict()
-    for name, shape in hrnet_param_shapes(extra, num_joints, target_type).items():
+    for name, shape in hrnet_param_shapes(extra, num_joints, target_type, psa=psa).items():
         if name.endswith("num_batches_tracked"):
             sd[name] = torch.tensor(0, dtype=torch.long)
             continue
