@@ -21,9 +21,10 @@ BN_EPS = 1e-5
 
 
 class _Net:
-    def __init__(self, sd, calibrate=False):
+    def __init__(self, sd, calibrate=False, train=False):
         self.sd = sd
         self.calibrate = calibrate
+        self.train = train
 
     def conv(self, x, name, stride=1, pad=None):
         w = self.sd[name + ".weight"]
@@ -37,6 +38,12 @@ class _Net:
             var = x.var(dim=(0, 2, 3), unbiased=False)
             self.sd[name + ".running_mean"] = mean.clone()
             self.sd[name + ".running_var"] = var.clone()
+        if self.train:
+            # nn.BatchNorm2d in train mode: batch statistics, running stats updated in place with
+            # momentum 0.1 (BN_MOMENTUM pose_hrnet.py:20 == the nn default used by fuse/transition BNs)
+            return F.batch_norm(x, self.sd[name + ".running_mean"], self.sd[name + ".running_var"],
+                                self.sd[name + ".weight"], self.sd[name + ".bias"],
+                                training=True, momentum=0.1, eps=BN_EPS)
         return F.batch_norm(x, self.sd[name + ".running_mean"], self.sd[name + ".running_var"],
                             self.sd[name + ".weight"], self.sd[name + ".bias"],
                             training=False, eps=BN_EPS)
@@ -140,7 +147,16 @@ def hrnet_forward(sd, extra, x, calibrate=False, taps=None):
     """pose_hrnet.py:436-471.  ``sd``: reference state_dict (fp32 tensors),
     ``extra``: MODEL.EXTRA dict, ``x``: [N,3,H,W] fp32.  Optional ``taps``
     dict receives named intermediate activations."""
-    net = _Net(sd, calibrate)
+    return _forward(_Net(sd, calibrate), extra, x, taps)
+
+
+def hrnet_forward_train(sd, extra, x, taps=None):
+    """Same graph under ``model.train()`` (function.py:38): BatchNorm on batch statistics, running
+    statistics of ``sd`` updated in place; autograd is left on so the caller can back-propagate."""
+    return _forward(_Net(sd, train=True), extra, x, taps)
+
+
+def _forward(net, extra, x, taps=None):
     x = F.relu(net.bn(net.conv(x, "conv1", stride=2), "bn1"))
     x = F.relu(net.bn(net.conv(x, "conv2", stride=2), "bn2"))
     if taps is not None:
