@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UDP_POSE_ABI_VERSION 3
+#define UDP_POSE_ABI_VERSION 4
 
 enum udp_status {
   UDP_OK = 0,
@@ -196,6 +196,63 @@ int udp_target_offset(const float* joints, const float* vis, int n, int j, int i
  * ------------------------------------------------------------------------- */
 int udp_mse_loss(const float* pred, const float* target, const float* weight, int b, int j, int hw,
                  int is_offset, double* loss_out, float* grad, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Training step (deep_hrnet/lib/core/function.py:38-77: model.train(), forward,
+ * criterion, zero_grad / backward / step; optimizer lib/utils/utils.py:70-74).
+ * Activations are NHWC `dtype` with the channel count rounded up to 16 (zero
+ * filled); parameters, gradients and optimizer state are fp32 in the reference's
+ * state_dict layouts.  The host (udp-pose_amd/train.py) keeps the tape.
+ * ------------------------------------------------------------------------- */
+/* conv weight [cout][cin][ks][ks] fp32 -> operand layouts of udp_conv2d_fused:
+ *   w_fwd   [ks*ks][cout_pad=ceil32(cout)][cin_k=ceil16(cin)]                      (forward)
+ *   w_dgrad [ks*ks][ceil32(cin)][ceil16(cout)], taps mirrored, Cin/Cout swapped  (input gradient;
+ *           may be NULL).  conv2d backward w.r.t. the input of a stride-1 conv is
+ *   udp_conv2d_fused(dy, w_dgrad); for stride 2 apply it to udp_zero_stuff2(dy). */
+int udp_pack_conv_weights(const float* w, int cout, int cin, int ks, int dtype, void* w_fwd,
+                          void* w_dgrad, void* stream);
+/* out[n][2y][2x][c] = dy[n][y][x][c], zero elsewhere (out: [n][2h][2w][c]). */
+int udp_zero_stuff2(const void* dy, int n, int h, int w, int c, int dtype, void* out, void* stream);
+/* dW[co][ci][ky][kx] (+)= sum_{n,y,x} dy[n,y,x,co] * x[n, y*s+ky-ks/2, x*s+kx-ks/2, ci]
+ * (torch.nn.functional.conv2d backward w.r.t. weight).  x: [n,hin,win,cin_k], dy: [n,hout,wout,cout_k].
+ * workspace: split-K partials, at least ks*ks*cout*cin*4 bytes (udp_conv2d_wgrad_workspace_bytes
+ * suggests a size that keeps the chip full). */
+size_t udp_conv2d_wgrad_workspace_bytes(int cout, int cin, int ks);
+int udp_conv2d_wgrad(const void* x, const void* dy, int n, int hin, int win, int cin_k, int hout,
+                     int wout, int cout_k, int ks, int stride, int cout, int cin, int dtype, float* dw,
+                     int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* nn.BatchNorm2d in train mode over x [m = N*H*W rows][c]: batch mean / biased variance (fp64 sums),
+ * running_mean/var <- (1-momentum)*running + momentum*batch (unbiased variance), either may be NULL;
+ * y = [relu](xhat*gamma + beta [+ res]).  save_mean / save_invstd fp32 [c] feed the backward.
+ * ws: 2*c doubles of scratch. */
+int udp_bn_train_fwd(const void* x, int64_t m, int c, const float* gamma, const float* beta, float eps,
+                     float momentum, float* running_mean, float* running_var, float* save_mean,
+                     float* save_invstd, const void* res, int relu, void* y, int dtype, double* ws,
+                     void* stream);
+/* Backward of the above.  g = dy * (y_relu > 0) when y_relu != NULL (the ReLU that followed), else dy.
+ * dgamma = sum g*xhat, dbeta = sum g, dx = gamma*invstd*(g - dbeta/m - xhat*dgamma/m);
+ * g_out (optional) receives g -- the gradient of the residual input. */
+int udp_bn_train_bwd(const void* x, const void* dy, const void* y_relu, int64_t m, int c,
+                     const float* gamma, const float* save_mean, const float* save_invstd, float* dgamma,
+                     float* dbeta, void* dx, void* g_out, int dtype, double* ws, void* stream);
+/* acc[n,y,x,c] (init ? = : +=) src[n, y>>shift, x>>shift, c], optional ReLU: the sum nodes of
+ * HighResolutionModule.forward (pose_hrnet.py:266-272) with nn.Upsample(mode='nearest'). */
+int udp_ew_accumulate(void* acc, const void* src, int n, int h, int w, int c, int shift, int init,
+                      int relu, int dtype, void* stream);
+/* g = dy * (y > 0). */
+int udp_relu_bwd(const void* dy, const void* y, void* g, int64_t count, int dtype, void* stream);
+/* Backward of nearest upsampling by 2^shift: du[n,y,x,c] (+)= sum of the 2^shift x 2^shift block of g
+ * (g: [n,h,w,c], du: [n,h>>shift,w>>shift,c]). */
+int udp_upsample_bwd(const void* g, int n, int h, int w, int c, int shift, void* du, int accumulate,
+                     int dtype, void* stream);
+/* db[c] = sum over the m rows of g[row*c_pitch + c] (conv bias gradient). */
+int udp_bias_grad(const void* g, int64_t m, int c_pitch, int c, float* db, int dtype, void* stream);
+/* NCHW fp32 [n,c,h,w] -> NHWC `dtype` [n,h,w,c_pad], channels c..c_pad zero. */
+int udp_nchw_to_nhwc(const float* src, int n, int c, int h, int w, int c_pad, void* dst, int dtype,
+                     void* stream);
+/* torch.optim.Adam (no weight decay, no amsgrad) over flat fp32 buffers; step counts from 1. */
+int udp_adam_step(float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1,
+                  float beta2, float eps, int step, void* stream);
 
 #ifdef __cplusplus
 }

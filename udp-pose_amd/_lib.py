@@ -15,7 +15,7 @@ UDP_F32, UDP_BF16 = 0, 1
 UDP_OP_STEM, UDP_OP_CONV, UDP_OP_FUSE, UDP_OP_STEM7, UDP_OP_MAXPOOL, UDP_OP_BILINEAR = 0, 1, 2, 3, 4, 5
 UDP_OP_PSA_POOL, UDP_OP_PSA_MLP, UDP_OP_PSA_SCALE, UDP_OP_PSA_SP = 6, 7, 8, 9
 UDP_BUF_NONE, UDP_BUF_OUTPUT = -1, -2
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_LANES, MAX_WAIT = 4, 8
 
 
@@ -67,6 +67,21 @@ _SIGS = {
     "udp_target_offset": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_float, _P, _P, _P]),
     "udp_mse_loss": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    # training step
+    "udp_pack_conv_weights": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "udp_zero_stuff2": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "udp_conv2d_wgrad_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "udp_conv2d_wgrad": (C.c_int, [_P, _P] + [C.c_int] * 12 + [_P, C.c_int, _P, C.c_size_t, _P]),
+    "udp_bn_train_fwd": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P, _P,
+                                   C.c_int, _P, C.c_int, _P, _P]),
+    "udp_bn_train_bwd": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
+    "udp_ew_accumulate": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, _P]),
+    "udp_relu_bwd": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, _P]),
+    "udp_upsample_bwd": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P]),
+    "udp_bias_grad": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, _P, C.c_int, _P]),
+    "udp_nchw_to_nhwc": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
+    "udp_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, _P]),
 }
 EXPORTS = tuple(_SIGS)
 

@@ -1,0 +1,609 @@
+// Training-step kernels for gfx950: what loss.backward() / optimizer.step() of
+// deep_hrnet/lib/core/function.py:73-76 run for the HRNet graph of lib/models/pose_hrnet.py.
+//
+//   conv forward / input gradient : the implicit-GEMM kernel of conv.hip (udp_conv2d_fused) on weights
+//                                   re-packed here each step (udp_pack_conv_weights): the input gradient
+//                                   of a stride-1 conv is a stride-1 conv of dy with the taps mirrored and
+//                                   Cin/Cout swapped; stride 2 goes through udp_zero_stuff2 first.
+//   conv weight gradient          : udp_conv2d_wgrad, MFMA fp32 16x16x4, K = pixels (split-K partials +
+//                                   one deterministic reduce).
+//   BatchNorm2d (train mode)      : batch statistics in fp64, running-stat update, fused (+res)(+ReLU)
+//                                   apply; backward with the ReLU mask folded in.
+//   nearest-upsample / sum nodes  : udp_ew_accumulate, udp_upsample_bwd, udp_relu_bwd.
+//   Adam                          : one launch over the flat parameter / gradient buffers.
+//
+// Tensors are NHWC `dtype` (fp32, or bf16 storage with fp32 arithmetic); parameters, gradients and
+// optimizer state are fp32 in the reference's own layouts ([cout][cin][kh][kw]).
+#include <type_traits>
+
+#include "common.h"
+
+namespace udp {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T>
+__device__ __forceinline__ float tof(T v) {
+  return (float)v;
+}
+template <typename T>
+__device__ __forceinline__ T fromf(float v) {
+  return (T)v;
+}
+
+static inline int rup(int x, int m) { return (x + m - 1) / m * m; }
+static inline unsigned nblocks(long total, int per, long cap = 1 << 20) {
+  long b = (total + per - 1) / per;
+  if (b < 1) b = 1;
+  return (unsigned)(b > cap ? cap : b);
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight re-pack: reference [cout][cin][ks][ks] fp32 ->
+//   fwd   [tap][cout_pad][cin_k]            (cin_k = cin rounded up to 16, cout_pad to 32; zero filled)
+//   dgrad [tap'][cin_pad][cout_k], tap' = mirrored tap, value W[co][ci][ks-1-ky'][ks-1-kx']
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_weights_kernel(const float* __restrict__ w, int cout, int cin, int ks, int cout_pad, int cin_k,
+                                    int cin_pad, int cout_k, T* __restrict__ fwd, T* __restrict__ dg) {
+  const int taps = ks * ks;
+  const long nf = (long)taps * cout_pad * cin_k;
+  const long nd = dg ? (long)taps * cin_pad * cout_k : 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nf + nd; i += (long)gridDim.x * blockDim.x) {
+    if (i < nf) {
+      const int ci = i % cin_k, co = (i / cin_k) % cout_pad, t = i / ((long)cin_k * cout_pad);
+      fwd[i] = fromf<T>((co < cout && ci < cin) ? w[((long)co * cin + ci) * taps + t] : 0.f);
+    } else {
+      const long k = i - nf;
+      const int co = k % cout_k, ci = (k / cout_k) % cin_pad, t = k / ((long)cout_k * cin_pad);
+      dg[k] = fromf<T>((co < cout && ci < cin) ? w[((long)co * cin + ci) * taps + (taps - 1 - t)] : 0.f);
+    }
+  }
+}
+
+// out[n][2y][2x][c] = in[n][y][x][c], zeros elsewhere
+template <typename T>
+__global__ void zero_stuff2_kernel(const T* __restrict__ in, long total_out, int h, int w, int c, T* __restrict__ out) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total_out; i += (long)gridDim.x * blockDim.x) {
+    const int ch = i % c;
+    long r = i / c;
+    const int x = r % (2 * w);
+    r /= 2 * w;
+    const int y = r % (2 * h);
+    const long n = r / (2 * h);
+    out[i] = ((x | y) & 1) ? fromf<T>(0.f) : in[((n * h + (y >> 1)) * w + (x >> 1)) * c + ch];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient.  dW[co][ci][ky][kx] = sum_{n,y,x} dy[n,y,x,co] * x[n, y*s+ky-pad, x*s+kx-pad, ci]
+// Workgroup = 32 co x 32 ci x all taps over `upw` pixel units; unit = TH x TW output pixels of one
+// image staged in LDS with the matching input patch.  MFMA 16x16x4 fp32: A[m=co][k=pixel],
+// B[k=pixel][n=ci]; wave w owns the 16x16 tile (w&1, w>>1) for every tap.
+// Partials go to part[split][tap][co][ci]; wgrad_reduce_kernel sums the splits.
+// ---------------------------------------------------------------------------------------------
+struct WgradParams {
+  const void* x;
+  const void* dy;
+  float* part;
+  int N, Hin, Win, CinK, Hout, Wout, CoutK, stride;
+  int TH, TW, units_y, units_x, units, upw;   // units per image / total / per workgroup
+  int XH, XW, tiles_ci;
+  int cout, cin;
+};
+
+constexpr int kWgPitch = 36;   // floats per staged pixel (32 channels + 4: 16-byte aligned, bank spread)
+
+template <typename T, int KS>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
+  extern __shared__ float lds[];
+  constexpr int TAPS = KS * KS, PAD = KS / 2;
+  const int PX = p.TH * p.TW, PXP = (PX + 3) & ~3;
+  float* sDy = lds;                       // [PXP][pitch]
+  float* sX = lds + PXP * kWgPitch;       // [XH*XW][pitch]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int ci0 = (blockIdx.x % p.tiles_ci) * 32, co0 = (blockIdx.x / p.tiles_ci) * 32;
+  const int mt = wave & 1, nt = wave >> 1;
+  const T* gx = reinterpret_cast<const T*>(p.x);
+  const T* gdy = reinterpret_cast<const T*>(p.dy);
+  f32x4 acc[TAPS];
+#pragma unroll
+  for (int i = 0; i < TAPS; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int u0 = blockIdx.y * p.upw, u1 = min(u0 + p.upw, p.units);
+  const int upi = p.units_y * p.units_x;
+  for (int u = u0; u < u1; ++u) {
+    const int n = u / upi, ur = u % upi;
+    const int oy0 = (ur / p.units_x) * p.TH, ox0 = (ur % p.units_x) * p.TW;
+    __syncthreads();   // previous unit's MFMA reads are done
+    // dy tile: pixel q -> (oy0 + q / TW, ox0 + q % TW); 8 threads x 4 channels per pixel
+    for (int i = t; i < PXP * 8; i += 256) {
+      const int q = i >> 3, c4 = (i & 7) * 4;
+      const int oy = oy0 + q / p.TW, ox = ox0 + q % p.TW;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (q < PX && oy < p.Hout && ox < p.Wout && co0 + c4 < p.CoutK) {
+        const T* s = gdy + (((long)n * p.Hout + oy) * p.Wout + ox) * p.CoutK + co0 + c4;
+        v = f32x4{tof(s[0]), tof(s[1]), tof(s[2]), tof(s[3])};
+      }
+      *reinterpret_cast<f32x4*>(sDy + q * kWgPitch + c4) = v;
+    }
+    const int iy0 = oy0 * p.stride - PAD, ix0 = ox0 * p.stride - PAD;
+    for (int i = t; i < p.XH * p.XW * 8; i += 256) {
+      const int q = i >> 3, c4 = (i & 7) * 4;
+      const int iy = iy0 + q / p.XW, ix = ix0 + q % p.XW;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win && ci0 + c4 < p.CinK) {
+        const T* s = gx + (((long)n * p.Hin + iy) * p.Win + ix) * p.CinK + ci0 + c4;
+        v = f32x4{tof(s[0]), tof(s[1]), tof(s[2]), tof(s[3])};
+      }
+      *reinterpret_cast<f32x4*>(sX + q * kWgPitch + c4) = v;
+    }
+    __syncthreads();
+    for (int k0 = 0; k0 < PXP; k0 += 4) {
+      int q = k0 + (lane >> 4);
+      const float a = sDy[q * kWgPitch + mt * 16 + (lane & 15)];
+      q = min(q, PX - 1);               // padded pixels carry dy == 0; keep the x address inside the tile
+      const int ty = q / p.TW, tx = q % p.TW;
+      const float* bx = sX + ((ty * p.stride) * p.XW + tx * p.stride) * kWgPitch + nt * 16 + (lane & 15);
+#pragma unroll
+      for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx)
+          acc[ky * KS + kx] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bx[(ky * p.XW + kx) * kWgPitch], acc[ky * KS + kx], 0, 0, 0);
+    }
+  }
+  // D[m = 4*(lane/16)+r][n = lane%16]
+  const int ci = ci0 + nt * 16 + (lane & 15);
+  float* dst = p.part + (long)blockIdx.y * TAPS * p.cout * p.cin;
+  if (ci < p.cin) {
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + mt * 16 + 4 * (lane >> 4) + r;
+        if (co < p.cout) dst[((long)tp * p.cout + co) * p.cin + ci] = acc[tp][r];
+      }
+  }
+}
+
+// dw[co][ci][tap] (+)= sum_s part[s][tap][co][ci]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int splits, int taps, int cout, int cin,
+                                    int accumulate, float* __restrict__ dw) {
+  const long per = (long)taps * cout * cin;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += part[k * per + i];
+    const int ci = i % cin, co = (i / cin) % cout, tp = i / ((long)cin * cout);
+    float* d = dw + ((long)co * cin + ci) * taps + tp;
+    *d = accumulate ? *d + s : s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm2d, train mode (nn.BatchNorm2d.forward with self.training; pose_hrnet.py:36-57 etc.)
+// ---------------------------------------------------------------------------------------------
+// ws[0..C) += sum_rows a*b?  generic per-channel sums of two row functions, fp64.
+//   MODE 0: (x, x*x)                       forward statistics
+//   MODE 1: (g, g*xhat), g = dy*(y>0)      backward sums
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void bn_sums_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                      const T* __restrict__ y, const float* __restrict__ mean,
+                                                      const float* __restrict__ invstd, long m, int C, int rows_per_block,
+                                                      double* __restrict__ ws) {
+  __shared__ double red[2][256];
+  const int t = threadIdx.x;
+  const int CT = C < 256 ? C : 256, RG = 256 / CT;
+  const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, m);
+  for (int cb = 0; cb < C; cb += CT) {
+    const int c = cb + t % CT;
+    double s0 = 0.0, s1 = 0.0;
+    if (t < RG * CT && c < C) {
+      float mu = 0.f, is = 1.f;
+      if (MODE == 1) {
+        mu = mean[c];
+        is = invstd[c];
+      }
+      for (long r = r0 + t / CT; r < r1; r += RG) {
+        const float xv = tof(x[r * C + c]);
+        if (MODE == 0) {
+          s0 += xv;
+          s1 += (double)xv * xv;
+        } else {
+          float g = tof(dy[r * C + c]);
+          if (y && !(tof(y[r * C + c]) > 0.f)) g = 0.f;
+          s0 += g;
+          s1 += (double)g * ((xv - mu) * is);
+        }
+      }
+    }
+    red[0][t] = s0;
+    red[1][t] = s1;
+    __syncthreads();
+    if (t < CT && cb + t < C) {
+      double a = 0.0, b = 0.0;
+      for (int g = 0; g < RG; ++g) {
+        a += red[0][g * CT + t];
+        b += red[1][g * CT + t];
+      }
+      atomicAdd(&ws[cb + t], a);
+      atomicAdd(&ws[C + cb + t], b);
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void bn_fwd_finalize_kernel(const double* __restrict__ ws, long m, int C, float eps, float momentum,
+                                       float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ smean,
+                                       float* __restrict__ sinvstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mu = ws[c] / (double)m;
+  double var = ws[C + c] / (double)m - mu * mu;
+  if (var < 0.0) var = 0.0;
+  smean[c] = (float)mu;
+  sinvstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mu;
+  if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(m > 1 ? var * (double)m / (double)(m - 1) : var);
+}
+
+// y = [relu]((x - mean) * invstd * gamma + beta [+ res])
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       long total, int C, int relu, T* __restrict__ y) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = i % C;
+    float v = (tof(x[i]) - mean[c]) * invstd[c] * gamma[c] + beta[c];
+    if (res) v += tof(res[i]);
+    if (relu) v = fmaxf(v, 0.f);
+    y[i] = fromf<T>(v);
+  }
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ ws, int C, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  dbeta[c] = (float)ws[c];
+  dgamma[c] = (float)ws[C + c];
+}
+
+// g = dy*(y>0);  dx = gamma*invstd*(g - dbeta/m - xhat*dgamma/m);  optional g_out = g
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                           const T* __restrict__ y, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const double* __restrict__ ws, long total, int C, float inv_m,
+                                                           T* __restrict__ dx, T* __restrict__ g_out) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = i % C;
+    float g = tof(dy[i]);
+    if (y && !(tof(y[i]) > 0.f)) g = 0.f;
+    const float xh = (tof(x[i]) - mean[c]) * invstd[c];
+    const float v = gamma[c] * invstd[c] * (g - (float)ws[c] * inv_m - xh * (float)ws[C + c] * inv_m);
+    dx[i] = fromf<T>(v);
+    if (g_out) g_out[i] = fromf<T>(g);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// element-wise nodes
+// ---------------------------------------------------------------------------------------------
+// acc[n,y,x,c] (init ? = : +=) src[n, y>>s, x>>s, c];  optional ReLU on the result
+template <typename T>
+__global__ __launch_bounds__(256) void ew_accumulate_kernel(T* __restrict__ acc, const T* __restrict__ src, long total,
+                                                            int h, int w, int c, int shift, int init, int relu) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    long j = i;
+    if (shift) {
+      const int ch = i % c;
+      long r = i / c;
+      const int x = r % w;
+      r /= w;
+      const int y = r % h;
+      const long n = r / h;
+      j = ((n * (h >> shift) + (y >> shift)) * (w >> shift) + (x >> shift)) * c + ch;
+    }
+    float v = tof(src[j]);
+    if (!init) v += tof(acc[i]);
+    if (relu) v = fmaxf(v, 0.f);
+    acc[i] = fromf<T>(v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, long total,
+                                                       T* __restrict__ g) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256)
+    g[i] = tof(y[i]) > 0.f ? dy[i] : fromf<T>(0.f);
+}
+
+// du[n,y,x,c] (+)= sum over the 2^s x 2^s block of g   (backward of nearest upsampling)
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__ g, long total_out, int h, int w, int c,
+                                                           int shift, int accumulate, T* __restrict__ du) {
+  const int hs = h >> shift, ws_ = w >> shift, f = 1 << shift;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total_out; i += (long)gridDim.x * 256) {
+    const int ch = i % c;
+    long r = i / c;
+    const int x = r % ws_;
+    r /= ws_;
+    const int y = r % hs;
+    const long n = r / hs;
+    float s = 0.f;
+    for (int dy = 0; dy < f; ++dy)
+      for (int dx = 0; dx < f; ++dx) s += tof(g[((n * h + (y * f + dy)) * w + (x * f + dx)) * c + ch]);
+    if (accumulate) s += tof(du[i]);
+    du[i] = fromf<T>(s);
+  }
+}
+
+// db[c] = sum_rows g[row*pitch + c]
+template <typename T>
+__global__ __launch_bounds__(256) void bias_grad_kernel(const T* __restrict__ g, long m, int pitch, int C,
+                                                        float* __restrict__ db) {
+  __shared__ double red[256];
+  const int c = blockIdx.x;
+  double s = 0.0;
+  for (long r = threadIdx.x; r < m; r += 256) s += tof(g[r * pitch + c]);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && c < C) db[c] = (float)red[0];
+}
+
+// NCHW fp32 [n,c,h,w] -> NHWC [n,h,w,c_pad] (zero filled channels c..c_pad)
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, long total, int c, int hw,
+                                                           int c_pad, T* __restrict__ dst) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int ch = i % c_pad;
+    const long r = i / c_pad;
+    const long n = r / hw, px = r % hw;
+    dst[i] = fromf<T>(ch < c ? src[(n * c + ch) * hw + px] : 0.f);
+  }
+}
+
+// torch.optim.Adam single-tensor rule (betas, eps; no weight decay, no amsgrad): lib/utils/utils.py:70-74
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long count, float b1, float b2, float eps,
+                                                   float step_size, float inv_sqrt_bc2) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) {
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = p[i] - step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+  }
+}
+
+#define UDP_DISPATCH_T(dtype, CALL_F32, CALL_BF16) \
+  do {                                             \
+    if ((dtype) == UDP_F32) {                      \
+      CALL_F32;                                    \
+    } else {                                       \
+      CALL_BF16;                                   \
+    }                                              \
+  } while (0)
+
+static int check_dtype(int dtype, const char* who) {
+  if (dtype != UDP_F32 && dtype != UDP_BF16) return fail(UDP_ERR_ARG, "%s: dtype %d", who, dtype);
+  return UDP_OK;
+}
+static int launched(const char* who) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(UDP_ERR_HIP, "%s: launch failed: %s", who, hipGetErrorString(e));
+  return UDP_OK;
+}
+
+}  // namespace udp
+
+using namespace udp;
+
+extern "C" int udp_pack_conv_weights(const float* w, int cout, int cin, int ks, int dtype, void* w_fwd, void* w_dgrad,
+                                     void* stream) {
+  if (!w || !w_fwd) return fail(UDP_ERR_ARG, "udp_pack_conv_weights: null pointer");
+  if (cout <= 0 || cin <= 0 || (ks != 1 && ks != 3)) return fail(UDP_ERR_ARG, "udp_pack_conv_weights: shape");
+  if (check_dtype(dtype, "udp_pack_conv_weights")) return UDP_ERR_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int cout_pad = rup(cout, 32), cin_k = rup(cin, 16), cin_pad = rup(cin, 32), cout_k = rup(cout, 16);
+  const long total = (long)ks * ks * ((long)cout_pad * cin_k + (w_dgrad ? (long)cin_pad * cout_k : 0));
+  UDP_DISPATCH_T(dtype,
+                 (pack_weights_kernel<float><<<nblocks(total, 256, 4096), 256, 0, s>>>(
+                     w, cout, cin, ks, cout_pad, cin_k, cin_pad, cout_k, (float*)w_fwd, (float*)w_dgrad)),
+                 (pack_weights_kernel<__bf16><<<nblocks(total, 256, 4096), 256, 0, s>>>(
+                     w, cout, cin, ks, cout_pad, cin_k, cin_pad, cout_k, (__bf16*)w_fwd, (__bf16*)w_dgrad)));
+  return launched("udp_pack_conv_weights");
+}
+
+extern "C" int udp_zero_stuff2(const void* dy, int n, int h, int w, int c, int dtype, void* out, void* stream) {
+  if (!dy || !out || n <= 0 || h <= 0 || w <= 0 || c <= 0) return fail(UDP_ERR_ARG, "udp_zero_stuff2: argument");
+  if (check_dtype(dtype, "udp_zero_stuff2")) return UDP_ERR_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const long total = (long)n * 4 * h * w * c;
+  UDP_DISPATCH_T(dtype, (zero_stuff2_kernel<float><<<nblocks(total, 256 * 4), 256, 0, s>>>((const float*)dy, total, h, w, c, (float*)out)),
+                 (zero_stuff2_kernel<__bf16><<<nblocks(total, 256 * 4), 256, 0, s>>>((const __bf16*)dy, total, h, w, c, (__bf16*)out)));
+  return launched("udp_zero_stuff2");
+}
+
+extern "C" size_t udp_conv2d_wgrad_workspace_bytes(int cout, int cin, int ks) {
+  // enough for 64 splits of the smallest layers, never less than 4 splits of the largest
+  const size_t per = (size_t)ks * ks * cout * cin * sizeof(float);
+  size_t want = per * 64;
+  const size_t cap = (size_t)64 << 20;
+  if (want > cap) want = cap;
+  if (want < per * 4) want = per * 4;
+  return want;
+}
+
+extern "C" int udp_conv2d_wgrad(const void* x, const void* dy, int n, int hin, int win, int cin_k, int hout, int wout,
+                                int cout_k, int ks, int stride, int cout, int cin, int dtype, float* dw, int accumulate,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  if (!x || !dy || !dw || !workspace) return fail(UDP_ERR_ARG, "udp_conv2d_wgrad: null pointer");
+  if (check_dtype(dtype, "udp_conv2d_wgrad")) return UDP_ERR_ARG;
+  if (n <= 0 || (ks != 1 && ks != 3) || (stride != 1 && stride != 2) || cout <= 0 || cin <= 0 || cout > cout_k ||
+      cin > cin_k || (cin_k & 3) || (cout_k & 3))
+    return fail(UDP_ERR_ARG, "udp_conv2d_wgrad: shape");
+  const int pad = ks / 2;
+  if (hout != (hin + 2 * pad - ks) / stride + 1 || wout != (win + 2 * pad - ks) / stride + 1)
+    return fail(UDP_ERR_ARG, "udp_conv2d_wgrad: output size does not match input/stride");
+  WgradParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = x;
+  p.dy = dy;
+  p.part = reinterpret_cast<float*>(workspace);
+  p.N = n; p.Hin = hin; p.Win = win; p.CinK = cin_k; p.Hout = hout; p.Wout = wout; p.CoutK = cout_k; p.stride = stride;
+  p.cout = cout; p.cin = cin;
+  const int maxpx = stride == 1 ? 64 : 32;
+  const int nseg = (wout + maxpx - 1) / maxpx;
+  p.TW = (wout + nseg - 1) / nseg;
+  p.TH = 1;
+  for (int th = maxpx / p.TW; th > 1; --th)
+    if (hout % th == 0) {
+      p.TH = th;
+      break;
+    }
+  p.units_x = (wout + p.TW - 1) / p.TW;
+  p.units_y = (hout + p.TH - 1) / p.TH;
+  p.units = n * p.units_x * p.units_y;
+  p.XH = (p.TH - 1) * stride + ks;
+  p.XW = (p.TW - 1) * stride + ks;
+  p.tiles_ci = (cin + 31) / 32;
+  const int tiles = p.tiles_ci * ((cout + 31) / 32);
+  const size_t per = (size_t)ks * ks * cout * cin * sizeof(float);
+  int splits = (2048 + tiles - 1) / tiles;                 // aim at >= 2048 workgroups
+  if (splits > p.units) splits = p.units;
+  if ((size_t)splits * per > workspace_bytes) splits = (int)(workspace_bytes / per);
+  if (splits < 1) return fail(UDP_ERR_ARG, "udp_conv2d_wgrad: workspace of %zu bytes is smaller than one partial (%zu)", workspace_bytes, per);
+  p.upw = (p.units + splits - 1) / splits;
+  splits = (p.units + p.upw - 1) / p.upw;
+  const int pxp = (p.TH * p.TW + 3) & ~3;
+  const unsigned lds = (unsigned)((pxp + p.XH * p.XW) * kWgPitch * sizeof(float));
+  if (lds > 160 * 1024) return fail(UDP_ERR_UNSUPPORTED, "udp_conv2d_wgrad: tile needs %u bytes of LDS", lds);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid(tiles, splits);
+  const void* fn;
+  if (dtype == UDP_F32)
+    fn = ks == 3 ? reinterpret_cast<const void*>(&wgrad_kernel<float, 3>) : reinterpret_cast<const void*>(&wgrad_kernel<float, 1>);
+  else
+    fn = ks == 3 ? reinterpret_cast<const void*>(&wgrad_kernel<__bf16, 3>) : reinterpret_cast<const void*>(&wgrad_kernel<__bf16, 1>);
+  if (lds > 64 * 1024) UDP_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  void* args[] = {&p};
+  UDP_HIP_CHECK(hipLaunchKernel(fn, grid, dim3(256), args, lds, s));
+  const long total = (long)ks * ks * cout * cin;
+  wgrad_reduce_kernel<<<nblocks(total, 256, 2048), 256, 0, s>>>(p.part, splits, ks * ks, cout, cin, accumulate, dw);
+  return launched("udp_conv2d_wgrad");
+}
+
+extern "C" int udp_bn_train_fwd(const void* x, int64_t m, int c, const float* gamma, const float* beta, float eps,
+                                float momentum, float* running_mean, float* running_var, float* save_mean,
+                                float* save_invstd, const void* res, int relu, void* y, int dtype, double* ws,
+                                void* stream) {
+  if (!x || !gamma || !beta || !save_mean || !save_invstd || !y || !ws) return fail(UDP_ERR_ARG, "udp_bn_train_fwd: null pointer");
+  if (m <= 0 || c <= 0) return fail(UDP_ERR_ARG, "udp_bn_train_fwd: m=%lld c=%d", (long long)m, c);
+  if (check_dtype(dtype, "udp_bn_train_fwd")) return UDP_ERR_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  UDP_HIP_CHECK(hipMemsetAsync(ws, 0, 2 * (size_t)c * sizeof(double), s));
+  const int rpb = (int)((m + 1023) / 1024 < 32 ? 32 : (m + 1023) / 1024);
+  const unsigned nb = nblocks(m, rpb);
+  UDP_DISPATCH_T(dtype,
+                 (bn_sums_kernel<float, 0><<<nb, 256, 0, s>>>((const float*)x, nullptr, nullptr, nullptr, nullptr, m, c, rpb, ws)),
+                 (bn_sums_kernel<__bf16, 0><<<nb, 256, 0, s>>>((const __bf16*)x, nullptr, nullptr, nullptr, nullptr, m, c, rpb, ws)));
+  bn_fwd_finalize_kernel<<<(c + 255) / 256, 256, 0, s>>>(ws, m, c, eps, momentum, running_mean, running_var, save_mean, save_invstd);
+  const long total = m * c;
+  UDP_DISPATCH_T(dtype,
+                 (bn_apply_kernel<float><<<nblocks(total, 256 * 4), 256, 0, s>>>((const float*)x, (const float*)res, save_mean, save_invstd, gamma, beta, total, c, relu, (float*)y)),
+                 (bn_apply_kernel<__bf16><<<nblocks(total, 256 * 4), 256, 0, s>>>((const __bf16*)x, (const __bf16*)res, save_mean, save_invstd, gamma, beta, total, c, relu, (__bf16*)y)));
+  return launched("udp_bn_train_fwd");
+}
+
+extern "C" int udp_bn_train_bwd(const void* x, const void* dy, const void* y_relu, int64_t m, int c, const float* gamma,
+                                const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, void* dx,
+                                void* g_out, int dtype, double* ws, void* stream) {
+  if (!x || !dy || !gamma || !save_mean || !save_invstd || !dgamma || !dbeta || !dx || !ws)
+    return fail(UDP_ERR_ARG, "udp_bn_train_bwd: null pointer");
+  if (m <= 0 || c <= 0) return fail(UDP_ERR_ARG, "udp_bn_train_bwd: m=%lld c=%d", (long long)m, c);
+  if (check_dtype(dtype, "udp_bn_train_bwd")) return UDP_ERR_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  UDP_HIP_CHECK(hipMemsetAsync(ws, 0, 2 * (size_t)c * sizeof(double), s));
+  const int rpb = (int)((m + 1023) / 1024 < 32 ? 32 : (m + 1023) / 1024);
+  const unsigned nb = nblocks(m, rpb);
+  UDP_DISPATCH_T(dtype,
+                 (bn_sums_kernel<float, 1><<<nb, 256, 0, s>>>((const float*)x, (const float*)dy, (const float*)y_relu, save_mean, save_invstd, m, c, rpb, ws)),
+                 (bn_sums_kernel<__bf16, 1><<<nb, 256, 0, s>>>((const __bf16*)x, (const __bf16*)dy, (const __bf16*)y_relu, save_mean, save_invstd, m, c, rpb, ws)));
+  bn_bwd_finalize_kernel<<<(c + 255) / 256, 256, 0, s>>>(ws, c, dgamma, dbeta);
+  const long total = m * c;
+  const float inv_m = 1.f / (float)m;
+  UDP_DISPATCH_T(dtype,
+                 (bn_bwd_apply_kernel<float><<<nblocks(total, 256 * 4), 256, 0, s>>>((const float*)x, (const float*)dy, (const float*)y_relu, save_mean, save_invstd, gamma, ws, total, c, inv_m, (float*)dx, (float*)g_out)),
+                 (bn_bwd_apply_kernel<__bf16><<<nblocks(total, 256 * 4), 256, 0, s>>>((const __bf16*)x, (const __bf16*)dy, (const __bf16*)y_relu, save_mean, save_invstd, gamma, ws, total, c, inv_m, (__bf16*)dx, (__bf16*)g_out)));
+  return launched("udp_bn_train_bwd");
+}
+
+extern "C" int udp_ew_accumulate(void* acc, const void* src, int n, int h, int w, int c, int shift, int init, int relu,
+                                 int dtype, void* stream) {
+  if (!acc || !src || n <= 0 || h <= 0 || w <= 0 || c <= 0) return fail(UDP_ERR_ARG, "udp_ew_accumulate: argument");
+  if (shift < 0 || shift > 5 || (h & ((1 << shift) - 1)) || (w & ((1 << shift) - 1)))
+    return fail(UDP_ERR_ARG, "udp_ew_accumulate: shift %d does not divide %dx%d", shift, h, w);
+  if (check_dtype(dtype, "udp_ew_accumulate")) return UDP_ERR_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const long total = (long)n * h * w * c;
+  UDP_DISPATCH_T(dtype, (ew_accumulate_kernel<float><<<nblocks(total, 256 * 4), 256, 0, s>>>((float*)acc, (const float*)src, total, h, w, c, shift, init, relu)),
+                 (ew_accumulate_kernel<__bf16><<<nblocks(total, 256 * 4), 256, 0, s>>>((__bf16*)acc, (const __bf16*)src, total, h, w, c, shift, init, relu)));
+  return launched("udp_ew_accumulate");
+}
+
+extern "C" int udp_relu_bwd(const void* dy, const void* y, void* g, int64_t count, int dtype, void* stream) {
+  if (!dy || !y || !g || count <= 0) return fail(UDP_ERR_ARG, "udp_relu_bwd: argument");
+  if (check_dtype(dtype, "udp_relu_bwd")) return UDP_ERR_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  UDP_DISPATCH_T(dtype, (relu_bwd_kernel<float><<<nblocks(count, 256 * 4), 256, 0, s>>>((const float*)dy, (const float*)y, count, (float*)g)),
+                 (relu_bwd_kernel<__bf16><<<nblocks(count, 256 * 4), 256, 0, s>>>((const __bf16*)dy, (const __bf16*)y, count, (__bf16*)g)));
+  return launched("udp_relu_bwd");
+}
+
+extern "C" int udp_upsample_bwd(const void* g, int n, int h, int w, int c, int shift, void* du, int accumulate, int dtype,
+                                void* stream) {
+  if (!g || !du || n <= 0 || h <= 0 || w <= 0 || c <= 0) return fail(UDP_ERR_ARG, "udp_upsample_bwd: argument");
+  if (shift < 1 || shift > 5 || (h & ((1 << shift) - 1)) || (w & ((1 << shift) - 1)))
+    return fail(UDP_ERR_ARG, "udp_upsample_bwd: shift %d does not divide %dx%d", shift, h, w);
+  if (check_dtype(dtype, "udp_upsample_bwd")) return UDP_ERR_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const long total = (long)n * (h >> shift) * (w >> shift) * c;
+  UDP_DISPATCH_T(dtype, (upsample_bwd_kernel<float><<<nblocks(total, 256), 256, 0, s>>>((const float*)g, total, h, w, c, shift, accumulate, (float*)du)),
+                 (upsample_bwd_kernel<__bf16><<<nblocks(total, 256), 256, 0, s>>>((const __bf16*)g, total, h, w, c, shift, accumulate, (__bf16*)du)));
+  return launched("udp_upsample_bwd");
+}
+
+extern "C" int udp_bias_grad(const void* g, int64_t m, int c_pitch, int c, float* db, int dtype, void* stream) {
+  if (!g || !db || m <= 0 || c <= 0 || c > c_pitch) return fail(UDP_ERR_ARG, "udp_bias_grad: argument");
+  if (check_dtype(dtype, "udp_bias_grad")) return UDP_ERR_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  UDP_DISPATCH_T(dtype, (bias_grad_kernel<float><<<c, 256, 0, s>>>((const float*)g, m, c_pitch, c, db)),
+                 (bias_grad_kernel<__bf16><<<c, 256, 0, s>>>((const __bf16*)g, m, c_pitch, c, db)));
+  return launched("udp_bias_grad");
+}
+
+extern "C" int udp_nchw_to_nhwc(const float* src, int n, int c, int h, int w, int c_pad, void* dst, int dtype, void* stream) {
+  if (!src || !dst || n <= 0 || c <= 0 || h <= 0 || w <= 0 || c_pad < c) return fail(UDP_ERR_ARG, "udp_nchw_to_nhwc: argument");
+  if (check_dtype(dtype, "udp_nchw_to_nhwc")) return UDP_ERR_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const long total = (long)n * h * w * c_pad;
+  UDP_DISPATCH_T(dtype, (nchw_to_nhwc_kernel<float><<<nblocks(total, 256 * 4), 256, 0, s>>>(src, total, c, h * w, c_pad, (float*)dst)),
+                 (nchw_to_nhwc_kernel<__bf16><<<nblocks(total, 256 * 4), 256, 0, s>>>(src, total, c, h * w, c_pad, (__bf16*)dst)));
+  return launched("udp_nchw_to_nhwc");
+}
+
+extern "C" int udp_adam_step(float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1, float beta2,
+                             float eps, int step, void* stream) {
+  if (!p || !g || !m || !v || count <= 0 || step < 1) return fail(UDP_ERR_ARG, "udp_adam_step: argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  adam_kernel<<<nblocks(count, 256 * 4), 256, 0, s>>>(p, g, m, v, count, beta1, beta2, eps, (float)((double)lr / bc1),
+                                                       (float)(1.0 / sqrt(bc2)));
+  return launched("udp_adam_step");
+}

@@ -1,0 +1,374 @@
+"""Training step on MI355X: the host side of deep_hrnet/lib/core/function.py:38-77.
+
+``HRNetTrainer`` owns the parameters (one flat fp32 buffer in ``named_parameters()`` order, so
+the gradient of the whole model is ONE contiguous bucket for the RCCL all-reduce), runs the
+train-mode forward of lib/models/pose_hrnet.py:436-471 op by op through the C ABI, keeps the tape
+and walks it backwards (``loss.backward()``), then ``udp_adam_step`` (``optimizer.step()``).
+torch is used for device memory only; every arithmetic step is a kernel of libudp_pose_hip.so.
+
+Reference contract mirrored: ``JointsMSELoss`` / ``JointsMSELoss_offset`` (lib/core/loss.py),
+``get_optimizer`` -> Adam(lr) (lib/utils/utils.py:60-76), ``train()`` (function.py:27-77) as
+``train_epoch``; multi-GPU replaces nn.DataParallel's implicit gradient reduction by an explicit
+mean all-reduce of the flat gradient (dist.allreduce_mean_).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .synth import hrnet_param_shapes
+
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+
+
+def _rup(x, m):
+    return (x + m - 1) // m * m
+
+
+def _is_param(k):
+    return not (k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked"))
+
+
+class _Act:
+    """An NHWC activation [n,h,w,ck] (ck = channels rounded up to 16) and its gradient."""
+    __slots__ = ("buf", "n", "h", "w", "c", "ck", "grad", "needs_grad")
+
+    def __init__(self, buf, n, h, w, c, ck, needs_grad=True):
+        self.buf, self.n, self.h, self.w, self.c, self.ck = buf, n, h, w, c, ck
+        self.grad = None
+        self.needs_grad = needs_grad
+
+
+class HRNetTrainer:
+    def __init__(self, cfg, state_dict, device="cuda", dtype="f32", lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        from .model import _get
+        self.extra = _get(cfg, "MODEL", "EXTRA")
+        self.num_joints = int(_get(cfg, "MODEL", "NUM_JOINTS"))
+        self.target_type = _get(cfg, "MODEL", "TARGET_TYPE")
+        self.device = torch.device(device)
+        self.dtype = dtype
+        self._dt = _lib.UDP_BF16 if dtype == "bf16" else _lib.UDP_F32
+        self._tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.step_count = 0
+        shapes = hrnet_param_shapes(self.extra, self.num_joints, self.target_type)
+        sd = {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+        missing = [k for k in shapes if k not in sd and not k.endswith("num_batches_tracked")]
+        if missing:
+            raise RuntimeError("state_dict lacks %d tensors, e.g. %s" % (len(missing), missing[:3]))
+        self._keys = [k for k in shapes if _is_param(k)]
+        self._stat_keys = [k for k in shapes if k.endswith("running_mean") or k.endswith("running_var")]
+        self._shapes = shapes
+        self._off, n = {}, 0
+        for k in self._keys + self._stat_keys:
+            self._off[k] = n
+            n += _rup(int(np.prod(shapes[k])), 4)
+        self._n_param = self._off[self._stat_keys[0]] if self._stat_keys else n
+        flat = torch.zeros(n, dtype=torch.float32)
+        for k in self._keys + self._stat_keys:
+            v = sd[k].detach().to(torch.float32).reshape(-1)
+            flat[self._off[k]:self._off[k] + v.numel()] = v
+        self.flat = flat.to(self.device)                 # parameters, then running statistics
+        self.grad = torch.zeros(self._n_param, dtype=torch.float32, device=self.device)
+        self.exp_avg = torch.zeros_like(self.grad)
+        self.exp_avg_sq = torch.zeros_like(self.grad)
+        # packed conv operands, refreshed from the fp32 master weights every step
+        self._convs = {}
+        esz = 2 if dtype == "bf16" else 4
+        ws_bytes = 0
+        for k in self._keys:
+            s = shapes[k]
+            if len(s) != 4:
+                continue
+            cout, cin, ks = s[0], s[1], s[2]
+            fwd = torch.empty(ks * ks * _rup(cout, 32) * _rup(cin, 16) * esz, dtype=torch.uint8, device=self.device)
+            dg = None
+            if k != "conv1.weight":
+                dg = torch.empty(ks * ks * _rup(cin, 32) * _rup(cout, 16) * esz, dtype=torch.uint8, device=self.device)
+            self._convs[k[:-len(".weight")]] = (cout, cin, ks, fwd, dg)
+            ws_bytes = max(ws_bytes, _lib.lib().udp_conv2d_wgrad_workspace_bytes(cout, cin, ks))
+        self._wgrad_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
+        self._zeros = torch.zeros(1024, dtype=torch.float32, device=self.device)      # zero bias rows
+        self._bn_ws = torch.empty(2 * 1024, dtype=torch.float64, device=self.device)
+        self._loss = torch.zeros(2, dtype=torch.float64, device=self.device)
+        self._tape = []
+
+    # ------------------------------------------------------------------ parameter views
+    def _p(self, key):
+        return self.flat.data_ptr() + 4 * self._off[key]
+
+    def _g(self, key):
+        return self.grad.data_ptr() + 4 * self._off[key]
+
+    def param(self, key):
+        n = int(np.prod(self._shapes[key]))
+        return self.flat[self._off[key]:self._off[key] + n].view(*self._shapes[key])
+
+    def grad_of(self, key):
+        n = int(np.prod(self._shapes[key]))
+        return self.grad[self._off[key]:self._off[key] + n].view(*self._shapes[key])
+
+    def state_dict(self):
+        """Reference-format state_dict (fp32, host) -- loadable by the reference module and by model.MODELS."""
+        flat = self.flat.cpu()
+        out = {}
+        for k, s in self._shapes.items():
+            if k.endswith("num_batches_tracked"):
+                out[k] = torch.tensor(self.step_count, dtype=torch.int64)
+            else:
+                n = int(np.prod(s))
+                out[k] = flat[self._off[k]:self._off[k] + n].view(*s).clone()
+        return out
+
+    # ------------------------------------------------------------------ primitive ops
+    def _stream(self):
+        return _lib.stream_ptr()
+
+    def _new(self, n, h, w, c, needs_grad=True):
+        ck = _rup(c, 16)
+        return _Act(torch.empty(n * h * w * ck, dtype=self._tdt, device=self.device), n, h, w, c, ck, needs_grad)
+
+    def _like(self, a):
+        return torch.empty_like(a.buf)
+
+    def _conv_op(self, ks, stride, cin, cout, hin, win, hout, wout, nchw=False):
+        op = _lib.ConvOp()
+        op.kind, op.ks, op.stride, op.relu = _lib.UDP_OP_CONV, ks, stride, 0
+        op.cin, op.cout, op.cout_pad = cin, cout, _rup(cout, 32)
+        op.hin, op.win, op.hout, op.wout = hin, win, hout, wout
+        op.in_buf = op.res_buf = _lib.UDP_BUF_NONE
+        op.out_buf = _lib.UDP_BUF_OUTPUT if nchw else 0
+        return op
+
+    def _conv(self, x, name, stride=1, bias_key=None, nchw_out=False):
+        L = _lib.lib()
+        cout, cin, ks, wf, wd = self._convs[name]
+        if x.c != cin:
+            raise ValueError("%s: expects %d input channels, got %d" % (name, cin, x.c))
+        pad = ks // 2
+        ho, wo = (x.h + 2 * pad - ks) // stride + 1, (x.w + 2 * pad - ks) // stride + 1
+        bias = self._p(bias_key) if bias_key else self._zeros.data_ptr()
+        if nchw_out:
+            y = _Act(torch.empty(x.n, cout, ho, wo, dtype=torch.float32, device=self.device), x.n, ho, wo, cout,
+                     _rup(cout, 16))
+            op = self._conv_op(ks, stride, x.ck, cout, x.h, x.w, ho, wo, nchw=True)
+        else:
+            y = self._new(x.n, ho, wo, cout)
+            op = self._conv_op(ks, stride, x.ck, y.ck, x.h, x.w, ho, wo)
+        if bias_key:                                       # bias row padded to cout_pad
+            b = torch.zeros(_rup(cout, 32), dtype=torch.float32, device=self.device)
+            b[:cout] = self.param(bias_key)
+            bias = b.data_ptr()
+            y_keep = b
+        else:
+            y_keep = None
+        _lib.check(L.udp_conv2d_fused(C.byref(op), self._dt, x.n, x.buf.data_ptr(), wf.data_ptr(), bias, None, None,
+                                      None, None, y.buf.data_ptr(), self._stream()))
+
+        def backward():
+            dy = y.grad                                   # NHWC [n,ho,wo,ck(cout)]
+            _lib.check(L.udp_conv2d_wgrad(x.buf.data_ptr(), dy.data_ptr(), x.n, x.h, x.w, x.ck, ho, wo, y.ck, ks,
+                                          stride, cout, cin, self._dt, self._g(name + ".weight"), 0,
+                                          self._wgrad_ws.data_ptr(), self._wgrad_ws.numel(), self._stream()))
+            if bias_key:
+                _lib.check(L.udp_bias_grad(dy.data_ptr(), x.n * ho * wo, y.ck, cout, self._g(bias_key), self._dt,
+                                           self._stream()))
+            if not x.needs_grad:
+                return
+            src, hh, ww = dy, ho, wo
+            if stride == 2:
+                src = torch.empty(x.n * 4 * ho * wo * y.ck, dtype=self._tdt, device=self.device)
+                _lib.check(L.udp_zero_stuff2(dy.data_ptr(), x.n, ho, wo, y.ck, self._dt, src.data_ptr(), self._stream()))
+                hh, ww = 2 * ho, 2 * wo
+            dop = self._conv_op(ks, 1, y.ck, x.ck, hh, ww, x.h, x.w)
+            res = x.grad
+            if res is None:
+                x.grad = self._like(x)
+            _lib.check(L.udp_conv2d_fused(C.byref(dop), self._dt, x.n, src.data_ptr(), wd.data_ptr(),
+                                          self._zeros.data_ptr(), None if res is None else res.data_ptr(), None, None,
+                                          None, x.grad.data_ptr(), self._stream()))
+        self._tape.append((y, backward, y_keep))
+        return y
+
+    def _bn(self, x, name, relu=True, res=None):
+        L = _lib.lib()
+        m, c = x.n * x.h * x.w, x.ck
+        if x.c != x.ck:
+            raise ValueError("%s: BatchNorm over %d channels (not a multiple of 16)" % (name, x.c))
+        y = self._new(x.n, x.h, x.w, x.c)
+        save = torch.empty(2 * c, dtype=torch.float32, device=self.device)
+        _lib.check(L.udp_bn_train_fwd(x.buf.data_ptr(), m, c, self._p(name + ".weight"), self._p(name + ".bias"),
+                                      BN_EPS, BN_MOMENTUM, self._p(name + ".running_mean"),
+                                      self._p(name + ".running_var"), save.data_ptr(), save.data_ptr() + 4 * c,
+                                      None if res is None else res.buf.data_ptr(), int(relu), y.buf.data_ptr(),
+                                      self._dt, self._bn_ws.data_ptr(), self._stream()))
+
+        def backward():
+            x.grad = self._like(x)
+            g_out = None
+            if res is not None and res.needs_grad:
+                g_out = self._like(y)
+            _lib.check(L.udp_bn_train_bwd(x.buf.data_ptr(), y.grad.data_ptr(), y.buf.data_ptr() if relu else None, m, c,
+                                          self._p(name + ".weight"), save.data_ptr(), save.data_ptr() + 4 * c,
+                                          self._g(name + ".weight"), self._g(name + ".bias"), x.grad.data_ptr(),
+                                          None if g_out is None else g_out.data_ptr(), self._dt,
+                                          self._bn_ws.data_ptr(), self._stream()))
+            if g_out is not None:
+                if res.grad is None:
+                    res.grad = g_out
+                else:
+                    _lib.check(L.udp_ew_accumulate(res.grad.data_ptr(), g_out.data_ptr(), res.n, res.h, res.w, res.ck,
+                                                   0, 0, 0, self._dt, self._stream()))
+        self._tape.append((y, backward, save))
+        return y
+
+    def _sum_relu(self, terms):
+        """y = relu(sum_k up(term_k, shift_k)): HighResolutionModule.forward :266-272."""
+        L = _lib.lib()
+        t0 = terms[0][0]
+        y = self._new(t0.n, t0.h << terms[0][1], t0.w << terms[0][1], t0.c)
+        for k, (t, s) in enumerate(terms):
+            _lib.check(L.udp_ew_accumulate(y.buf.data_ptr(), t.buf.data_ptr(), y.n, y.h, y.w, y.ck, s, int(k == 0),
+                                           int(k == len(terms) - 1), self._dt, self._stream()))
+
+        def backward():
+            g = self._like(y)
+            _lib.check(L.udp_relu_bwd(y.grad.data_ptr(), y.buf.data_ptr(), g.data_ptr(), g.numel(), self._dt,
+                                      self._stream()))
+            for t, s in terms:
+                if not t.needs_grad:
+                    continue
+                have = t.grad is not None
+                if not have:
+                    t.grad = self._like(t)
+                if s == 0:
+                    _lib.check(L.udp_ew_accumulate(t.grad.data_ptr(), g.data_ptr(), t.n, t.h, t.w, t.ck, 0, int(not have),
+                                                   0, self._dt, self._stream()))
+                else:
+                    _lib.check(L.udp_upsample_bwd(g.data_ptr(), y.n, y.h, y.w, y.ck, s, t.grad.data_ptr(), int(have),
+                                                  self._dt, self._stream()))
+        self._tape.append((y, backward, None))
+        return y
+
+    # ------------------------------------------------------------------ the HRNet graph (pose_hrnet.py)
+    def _basic(self, x, p):
+        t = self._bn(self._conv(x, p + ".conv1"), p + ".bn1")
+        return self._bn(self._conv(t, p + ".conv2"), p + ".bn2", res=x)
+
+    def _bottleneck(self, x, p):
+        a = self._bn(self._conv(x, p + ".conv1"), p + ".bn1")
+        b = self._bn(self._conv(a, p + ".conv2"), p + ".bn2")
+        r = x
+        if (p + ".downsample.0") in self._convs:
+            r = self._bn(self._conv(x, p + ".downsample.0"), p + ".downsample.1", relu=False)
+        return self._bn(self._conv(b, p + ".conv3"), p + ".bn3", res=r)
+
+    def _module(self, xs, p, num_blocks, last):
+        nb = len(xs)
+        xs = list(xs)
+        for b in range(nb):
+            for k in range(num_blocks[b]):
+                xs[b] = self._basic(xs[b], "%s.branches.%d.%d" % (p, b, k))
+        outs = []
+        for i in range(1 if last else nb):
+            terms = []
+            for j in range(nb):
+                q = "%s.fuse_layers.%d.%d" % (p, i, j)
+                if j > i:
+                    terms.append((self._bn(self._conv(xs[j], q + ".0"), q + ".1", relu=False), j - i))
+                elif j == i:
+                    terms.append((self._conv(xs[j], q + ".0") if last else xs[j], 0))
+                else:
+                    t = xs[j]
+                    for k in range(i - j):
+                        t = self._bn(self._conv(t, "%s.%d.0" % (q, k), stride=2), "%s.%d.1" % (q, k),
+                                     relu=(k != i - j - 1))
+                    terms.append((t, 0))
+            outs.append(self._sum_relu(terms))
+        return outs
+
+    def _transition(self, ys, name, n_cur):
+        xs = []
+        for i in range(n_cur):
+            q = "%s.%d" % (name, i)
+            if i < len(ys):
+                xs.append(self._bn(self._conv(ys[i], q + ".0"), q + ".1") if (q + ".0") in self._convs else ys[i])
+            else:
+                y = ys[-1]
+                for k in range(i + 1 - len(ys)):
+                    y = self._bn(self._conv(y, "%s.%d.0" % (q, k), stride=2), "%s.%d.1" % (q, k))
+                xs.append(y)
+        return xs
+
+    def forward(self, x):
+        """Train-mode forward.  x: fp32 [N,3,H,W] on the device.  Returns fp32 [N,C,H/4,W/4]."""
+        L = _lib.lib()
+        if x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3 or not x.is_contiguous():
+            raise ValueError("expected contiguous fp32 [N,3,H,W]")
+        n, _, h, w = x.shape
+        if h % 32 or w % 32:
+            raise ValueError("input %dx%d must be a multiple of 32" % (h, w))
+        self._tape = []
+        for name, (cout, cin, ks, wf, wd) in self._convs.items():
+            _lib.check(L.udp_pack_conv_weights(self._p(name + ".weight"), cout, cin, ks, self._dt, wf.data_ptr(),
+                                               None if wd is None else wd.data_ptr(), self._stream()))
+        a = self._new(n, h, w, 3, needs_grad=False)
+        _lib.check(L.udp_nchw_to_nhwc(x.data_ptr(), n, 3, h, w, a.ck, a.buf.data_ptr(), self._dt, self._stream()))
+        a = self._bn(self._conv(a, "conv1", stride=2), "bn1")
+        a = self._bn(self._conv(a, "conv2", stride=2), "bn2")
+        for k in range(4):
+            a = self._bottleneck(a, "layer1.%d" % k)
+        ys = [a]
+        for st in (2, 3, 4):
+            cfg = self.extra["STAGE%d" % st]
+            xs = self._transition(ys, "transition%d" % (st - 1), cfg["NUM_BRANCHES"])
+            for mi in range(cfg["NUM_MODULES"]):
+                xs = self._module(xs, "stage%d.%d" % (st, mi), cfg["NUM_BLOCKS"],
+                                  st == 4 and mi == cfg["NUM_MODULES"] - 1)
+            ys = xs
+        self._out = self._conv(ys[0], "final_layer", bias_key="final_layer.bias", nchw_out=True)
+        return self._out.buf
+
+    def backward(self, dheat):
+        """dheat: fp32 [N,C,h,w] = d loss / d heat-maps.  Fills self.grad (zero_grad is implicit: every
+        parameter gradient is overwritten)."""
+        L = _lib.lib()
+        o = self._out
+        g = torch.empty(o.n * o.h * o.w * o.ck, dtype=self._tdt, device=self.device)
+        _lib.check(L.udp_nchw_to_nhwc(dheat.data_ptr(), o.n, o.c, o.h, o.w, o.ck, g.data_ptr(), self._dt, self._stream()))
+        o.grad = g
+        for y, bwd, _ in reversed(self._tape):
+            if y.grad is not None:
+                bwd()
+            y.grad = None
+        self._tape = []
+
+    def loss_and_grad(self, heat, target, target_weight):
+        """criterion(output, target, target_weight) (loss.py:15-76) and its gradient w.r.t. output."""
+        b, c = heat.shape[:2]
+        off = self.target_type == "offset"
+        j = c // 3 if off else c
+        d = torch.empty_like(heat)
+        _lib.check(_lib.lib().udp_mse_loss(heat.data_ptr(), target.data_ptr(), target_weight.data_ptr(), b, j,
+                                           heat.shape[2] * heat.shape[3], int(off), self._loss.data_ptr(), d.data_ptr(),
+                                           self._stream()))
+        return self._loss, d
+
+    def adam_step(self):
+        """optimizer.step(): torch.optim.Adam(lr) on the flat parameter buffer (utils.py:70-74)."""
+        self.step_count += 1
+        _lib.check(_lib.lib().udp_adam_step(self.flat.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(),
+                                            self.exp_avg_sq.data_ptr(), self._n_param, self.lr, self.betas[0],
+                                            self.betas[1], self.eps, self.step_count, self._stream()))
+
+    def train_step(self, x, target, target_weight, world_size=1):
+        """function.py:46-76 for one batch.  Returns the loss tensor fp64 [2] = (L_hm, L_offset) on device."""
+        heat = self.forward(x)
+        loss, d = self.loss_and_grad(heat, target.contiguous(), target_weight.contiguous())
+        self.backward(d)
+        if world_size > 1:
+            from .dist import allreduce_mean_
+            allreduce_mean_(self.grad)
+        self.adam_step()
+        return loss
