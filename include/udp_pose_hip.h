@@ -224,7 +224,9 @@ int udp_conv2d_wgrad(const void* x, const void* dy, int n, int hin, int win, int
 /* nn.BatchNorm2d in train mode over x [m = N*H*W rows][c]: batch mean / biased variance (fp64 sums),
  * running_mean/var <- (1-momentum)*running + momentum*batch (unbiased variance), either may be NULL;
  * y = [relu](xhat*gamma + beta [+ res]).  save_mean / save_invstd fp32 [c] feed the backward.
- * ws: 2*c doubles of scratch. */
+ * c must be a multiple of 4.  ws: udp_bn_workspace_doubles(c) doubles of scratch (per-block partial
+ * sums, summed in a fixed order: results are run-to-run deterministic). */
+size_t udp_bn_workspace_doubles(int c);
 int udp_bn_train_fwd(const void* x, int64_t m, int c, const float* gamma, const float* beta, float eps,
                      float momentum, float* running_mean, float* running_var, float* save_mean,
                      float* save_invstd, const void* res, int relu, void* y, int dtype, double* ws,

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Config 3 (training step, function.py:38-77) timing on one GPU: W32 256x192, batch 32, Adam.
+Prints ms/step and images/s; `--prof` wraps nothing -- run under rocprofv3 --kernel-trace --stats."""
+import argparse, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from udp_pose_amd import synth
+from udp_pose_amd.train import HRNetTrainer
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=32)
+ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--warmup", type=int, default=2)
+ap.add_argument("--dtype", default="f32")
+ap.add_argument("--target", default="gaussian")
+a = ap.parse_args()
+nj = 17
+sd = synth.synth_state_dict(synth.W32_EXTRA, nj, a.target, seed=0)
+tr = HRNetTrainer({"MODEL": {"EXTRA": synth.W32_EXTRA, "NUM_JOINTS": nj, "TARGET_TYPE": a.target}}, sd, dtype=a.dtype)
+x = torch.from_numpy(synth.synth_crops(a.batch, 256, 192, seed=1)).cuda()
+c = nj * (3 if a.target == "offset" else 1)
+tg = torch.from_numpy(synth.synth_heatmaps(a.batch, nj, 64, 48, seed=2, channels_per_joint=c // nj)).cuda()
+tw = torch.ones(a.batch, nj, 1, device="cuda")
+for _ in range(a.warmup):
+    loss = tr.train_step(x, tg, tw)
+torch.cuda.synchronize()
+t0 = time.time()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(a.steps):
+    loss = tr.train_step(x, tg, tw)
+e1.record()
+torch.cuda.synchronize()
+wall = (time.time() - t0) / a.steps * 1e3
+dev = e0.elapsed_time(e1) / a.steps
+print("train W32 b=%d %s: %.1f ms/step (device %.1f ms), %.0f img/s, loss %s, peak mem %.1f GiB" % (
+    a.batch, a.dtype, wall, dev, a.batch / wall * 1e3, loss.cpu().numpy(), torch.cuda.max_memory_allocated() / 2**30))

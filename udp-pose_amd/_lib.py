@@ -72,6 +72,7 @@ _SIGS = {
     "udp_zero_stuff2": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "udp_conv2d_wgrad_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "udp_conv2d_wgrad": (C.c_int, [_P, _P] + [C.c_int] * 12 + [_P, C.c_int, _P, C.c_size_t, _P]),
+    "udp_bn_workspace_doubles": (C.c_size_t, [C.c_int]),
     "udp_bn_train_fwd": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P, _P,
                                    C.c_int, _P, C.c_int, _P, _P]),
     "udp_bn_train_bwd": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),

@@ -165,79 +165,160 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   }
 }
 
-// dw[co][ci][tap] (+)= sum_s part[s][tap][co][ci]
-__global__ void wgrad_reduce_kernel(const float* __restrict__ part, int splits, int taps, int cout, int cin,
-                                    int accumulate, float* __restrict__ dw) {
-  const long per = (long)taps * cout * cin;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per; i += (long)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += part[k * per + i];
-    const int ci = i % cin, co = (i / cin) % cout, tp = i / ((long)cin * cout);
-    float* d = dw + ((long)co * cin + ci) * taps + tp;
-    *d = accumulate ? *d + s : s;
+// dw[co][ci][tap] (+)= sum_s part[s][tap][co][ci].  Block = 16 element quads x 16 split lanes
+// (fixed summation order: deterministic).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int splits, int taps, int cout,
+                                                           int cin, int accumulate, float* __restrict__ dw) {
+  __shared__ f32x4 red[16][17];
+  const long per = (long)taps * cout * cin;          // multiple of 4? not necessarily: tail handled scalar
+  const int q = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const long i4 = ((long)blockIdx.x * 16 + q) * 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (i4 + 3 < per && (per & 3) == 0) {
+    for (int k = sl; k < splits; k += 16) s += *reinterpret_cast<const f32x4*>(part + k * per + i4);
+  } else {
+    for (int e = 0; e < 4; ++e)
+      if (i4 + e < per)
+        for (int k = sl; k < splits; k += 16) s[e] += part[k * per + i4 + e];
+  }
+  red[sl][q] = s;
+  __syncthreads();
+  if (sl == 0) {
+    for (int k = 1; k < 16; ++k) s += red[k][q];
+    for (int e = 0; e < 4; ++e) {
+      const long i = i4 + e;
+      if (i >= per) break;
+      const int ci = i % cin, co = (i / cin) % cout, tp = i / ((long)cin * cout);
+      float* d = dw + ((long)co * cin + ci) * taps + tp;
+      *d = accumulate ? *d + s[e] : s[e];
+    }
   }
 }
 
 // ---------------------------------------------------------------------------------------------
 // BatchNorm2d, train mode (nn.BatchNorm2d.forward with self.training; pose_hrnet.py:36-57 etc.)
 // ---------------------------------------------------------------------------------------------
-// ws[0..C) += sum_rows a*b?  generic per-channel sums of two row functions, fp64.
+// Per-channel partial sums of two row functions, fp64, one row of ws per block: ws[block][2C].
 //   MODE 0: (x, x*x)                       forward statistics
 //   MODE 1: (g, g*xhat), g = dy*(y>0)      backward sums
+// Thread = 4 consecutive channels (16-byte loads) x one row lane; C % 4 == 0.
+constexpr int kBnMaxBlocks = 512;
+
+template <typename T>
+__device__ __forceinline__ f32x4 ld4(const T* p) {
+  if constexpr (std::is_same<T, float>::value) {
+    return *reinterpret_cast<const f32x4*>(p);
+  } else {
+    return f32x4{tof(p[0]), tof(p[1]), tof(p[2]), tof(p[3])};
+  }
+}
+template <typename T>
+__device__ __forceinline__ void st4(T* p, f32x4 v) {
+  if constexpr (std::is_same<T, float>::value) {
+    *reinterpret_cast<f32x4*>(p) = v;
+  } else {
+    p[0] = fromf<T>(v[0]); p[1] = fromf<T>(v[1]); p[2] = fromf<T>(v[2]); p[3] = fromf<T>(v[3]);
+  }
+}
+
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void bn_sums_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                       const T* __restrict__ y, const float* __restrict__ mean,
-                                                      const float* __restrict__ invstd, long m, int C, int rows_per_block,
+                                                      const float* __restrict__ invstd, long m, int C,
                                                       double* __restrict__ ws) {
-  __shared__ double red[2][256];
+  __shared__ double red[256][8];
   const int t = threadIdx.x;
-  const int CT = C < 256 ? C : 256, RG = 256 / CT;
+  const int CG = C >> 2;                       // channel quads
+  const int CT = CG < 256 ? CG : 256, RG = 256 / CT;
+  const long rows_per_block = (m + gridDim.x - 1) / gridDim.x;
   const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, m);
-  for (int cb = 0; cb < C; cb += CT) {
-    const int c = cb + t % CT;
-    double s0 = 0.0, s1 = 0.0;
-    if (t < RG * CT && c < C) {
-      float mu = 0.f, is = 1.f;
+  double* out = ws + (long)blockIdx.x * 2 * C;
+  for (int cb = 0; cb < CG; cb += CT) {
+    const int cg = cb + t % CT;
+    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    if (t < RG * CT && cg < CG) {
+      f32x4 mu = {0.f, 0.f, 0.f, 0.f}, is = {1.f, 1.f, 1.f, 1.f};
       if (MODE == 1) {
-        mu = mean[c];
-        is = invstd[c];
+        mu = *reinterpret_cast<const f32x4*>(mean + cg * 4);
+        is = *reinterpret_cast<const f32x4*>(invstd + cg * 4);
       }
       for (long r = r0 + t / CT; r < r1; r += RG) {
-        const float xv = tof(x[r * C + c]);
+        const f32x4 xv = ld4(x + r * C + cg * 4);
         if (MODE == 0) {
-          s0 += xv;
-          s1 += (double)xv * xv;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            s0[e] += xv[e];
+            s1[e] += (double)xv[e] * xv[e];
+          }
         } else {
-          float g = tof(dy[r * C + c]);
-          if (y && !(tof(y[r * C + c]) > 0.f)) g = 0.f;
-          s0 += g;
-          s1 += (double)g * ((xv - mu) * is);
+          f32x4 g = ld4(dy + r * C + cg * 4);
+          if (y) {
+            const f32x4 yv = ld4(y + r * C + cg * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (!(yv[e] > 0.f)) g[e] = 0.f;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            s0[e] += g[e];
+            s1[e] += (double)g[e] * ((xv[e] - mu[e]) * is[e]);
+          }
         }
       }
     }
-    red[0][t] = s0;
-    red[1][t] = s1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[t][e] = s0[e];
+      red[t][4 + e] = s1[e];
+    }
     __syncthreads();
-    if (t < CT && cb + t < C) {
-      double a = 0.0, b = 0.0;
-      for (int g = 0; g < RG; ++g) {
-        a += red[0][g * CT + t];
-        b += red[1][g * CT + t];
+    if (t < CT && cb + t < CG) {
+      double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int g = 0; g < RG; ++g)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += red[g * CT + t][e];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        out[(cb + t) * 4 + e] = a[e];
+        out[C + (cb + t) * 4 + e] = a[4 + e];
       }
-      atomicAdd(&ws[cb + t], a);
-      atomicAdd(&ws[C + cb + t], b);
     }
     __syncthreads();
   }
 }
 
-__global__ void bn_fwd_finalize_kernel(const double* __restrict__ ws, long m, int C, float eps, float momentum,
+// Sum of the per-block partial rows for 16 channels per workgroup: 16 block lanes per channel, then a
+// fixed-order LDS reduction (deterministic).  Valid in threads with kl == 0.
+__device__ __forceinline__ void bn_collect(const double* ws, int nblocks, int C, int c, double& a, double& b) {
+  __shared__ double red[2][16][17];
+  const int cl = threadIdx.x & 15, kl = threadIdx.x >> 4;
+  a = 0.0;
+  b = 0.0;
+  if (c < C)
+    for (int k = kl; k < nblocks; k += 16) {
+      a += ws[(long)k * 2 * C + c];
+      b += ws[(long)k * 2 * C + C + c];
+    }
+  red[0][kl][cl] = a;
+  red[1][kl][cl] = b;
+  __syncthreads();
+  if (kl == 0) {
+    for (int k = 1; k < 16; ++k) {
+      a += red[0][k][cl];
+      b += red[1][k][cl];
+    }
+  }
+}
+
+__global__ void bn_fwd_finalize_kernel(double* __restrict__ ws, int nblocks, long m, int C, float eps, float momentum,
                                        float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ smean,
                                        float* __restrict__ sinvstd) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const double mu = ws[c] / (double)m;
-  double var = ws[C + c] / (double)m - mu * mu;
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+  double s0, s1;
+  bn_collect(ws, nblocks, C, c, s0, s1);
+  if (c >= C || (threadIdx.x >> 4)) return;
+  const double mu = s0 / (double)m;
+  double var = s1 / (double)m - mu * mu;
   if (var < 0.0) var = 0.0;
   smean[c] = (float)mu;
   sinvstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -245,27 +326,36 @@ __global__ void bn_fwd_finalize_kernel(const double* __restrict__ ws, long m, in
   if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(m > 1 ? var * (double)m / (double)(m - 1) : var);
 }
 
-// y = [relu]((x - mean) * invstd * gamma + beta [+ res])
+// y = [relu]((x - mean) * invstd * gamma + beta [+ res]); 4 channels per thread
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       long total, int C, int relu, T* __restrict__ y) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int c = i % C;
-    float v = (tof(x[i]) - mean[c]) * invstd[c] * gamma[c] + beta[c];
-    if (res) v += tof(res[i]);
-    if (relu) v = fmaxf(v, 0.f);
-    y[i] = fromf<T>(v);
+                                                       long total4, int C, int relu, T* __restrict__ y) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+    const int c = (int)((i * 4) % C);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
+    f32x4 v = (ld4(x + i * 4) - mu) * is * ga + be;
+    if (res) v += ld4(res + i * 4);
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    st4(y + i * 4, v);
   }
 }
 
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ ws, int C, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  dbeta[c] = (float)ws[c];
-  dgamma[c] = (float)ws[C + c];
+__global__ void bn_bwd_finalize_kernel(double* __restrict__ ws, int nblocks, int C, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, float* __restrict__ sums) {
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+  double s0, s1;
+  bn_collect(ws, nblocks, C, c, s0, s1);
+  if (c >= C || (threadIdx.x >> 4)) return;
+  dbeta[c] = (float)s0;
+  dgamma[c] = (float)s1;
+  sums[c] = (float)s0;
+  sums[C + c] = (float)s1;
 }
 
 // g = dy*(y>0);  dx = gamma*invstd*(g - dbeta/m - xhat*dgamma/m);  optional g_out = g
@@ -273,16 +363,23 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
                                                            const T* __restrict__ y, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                           const double* __restrict__ ws, long total, int C, float inv_m,
+                                                           const float* __restrict__ sums, long total4, int C, float inv_m,
                                                            T* __restrict__ dx, T* __restrict__ g_out) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int c = i % C;
-    float g = tof(dy[i]);
-    if (y && !(tof(y[i]) > 0.f)) g = 0.f;
-    const float xh = (tof(x[i]) - mean[c]) * invstd[c];
-    const float v = gamma[c] * invstd[c] * (g - (float)ws[c] * inv_m - xh * (float)ws[C + c] * inv_m);
-    dx[i] = fromf<T>(v);
-    if (g_out) g_out[i] = fromf<T>(g);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+    const int c = (int)((i * 4) % C);
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
+    const f32x4 db = *reinterpret_cast<const f32x4*>(sums + c), dg = *reinterpret_cast<const f32x4*>(sums + C + c);
+    f32x4 g = ld4(dy + i * 4);
+    if (y) {
+      const f32x4 yv = ld4(y + i * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (!(yv[e] > 0.f)) g[e] = 0.f;
+    }
+    const f32x4 xh = (ld4(x + i * 4) - mu) * is;
+    st4(dx + i * 4, ga * is * (g - db * inv_m - xh * dg * inv_m));
+    if (g_out) st4(g_out + i * 4, g);
   }
 }
 
@@ -394,6 +491,13 @@ static int check_dtype(int dtype, const char* who) {
   if (dtype != UDP_F32 && dtype != UDP_BF16) return fail(UDP_ERR_ARG, "%s: dtype %d", who, dtype);
   return UDP_OK;
 }
+// blocks of the BatchNorm partial-sum pass: >= 8 rows per row lane, at most kBnMaxBlocks
+static unsigned bn_blocks(long m, int c) {
+  const int cg = c / 4, ct = cg < 256 ? cg : 256, rg = 256 / ct;
+  long nb = m / ((long)rg * 8);
+  if (nb < 1) nb = 1;
+  return (unsigned)(nb > kBnMaxBlocks ? kBnMaxBlocks : nb);
+}
 static int launched(const char* who) {
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(UDP_ERR_HIP, "%s: launch failed: %s", who, hipGetErrorString(e));
@@ -475,7 +579,7 @@ extern "C" int udp_conv2d_wgrad(const void* x, const void* dy, int n, int hin, i
   p.tiles_ci = (cin + 31) / 32;
   const int tiles = p.tiles_ci * ((cout + 31) / 32);
   const size_t per = (size_t)ks * ks * cout * cin * sizeof(float);
-  int splits = (2048 + tiles - 1) / tiles;                 // aim at >= 2048 workgroups
+  int splits = (1024 + tiles - 1) / tiles;                 // aim at >= 1024 workgroups
   if (splits > p.units) splits = p.units;
   if ((size_t)splits * per > workspace_bytes) splits = (int)(workspace_bytes / per);
   if (splits < 1) return fail(UDP_ERR_ARG, "udp_conv2d_wgrad: workspace of %zu bytes is smaller than one partial (%zu)", workspace_bytes, per);
@@ -495,29 +599,29 @@ extern "C" int udp_conv2d_wgrad(const void* x, const void* dy, int n, int hin, i
   void* args[] = {&p};
   UDP_HIP_CHECK(hipLaunchKernel(fn, grid, dim3(256), args, lds, s));
   const long total = (long)ks * ks * cout * cin;
-  wgrad_reduce_kernel<<<nblocks(total, 256, 2048), 256, 0, s>>>(p.part, splits, ks * ks, cout, cin, accumulate, dw);
+  wgrad_reduce_kernel<<<nblocks(total, 64), 256, 0, s>>>(p.part, splits, ks * ks, cout, cin, accumulate, dw);
   return launched("udp_conv2d_wgrad");
 }
+
+extern "C" size_t udp_bn_workspace_doubles(int c) { return c > 0 ? (size_t)(kBnMaxBlocks + 1) * 2 * c : 0; }
 
 extern "C" int udp_bn_train_fwd(const void* x, int64_t m, int c, const float* gamma, const float* beta, float eps,
                                 float momentum, float* running_mean, float* running_var, float* save_mean,
                                 float* save_invstd, const void* res, int relu, void* y, int dtype, double* ws,
                                 void* stream) {
   if (!x || !gamma || !beta || !save_mean || !save_invstd || !y || !ws) return fail(UDP_ERR_ARG, "udp_bn_train_fwd: null pointer");
-  if (m <= 0 || c <= 0) return fail(UDP_ERR_ARG, "udp_bn_train_fwd: m=%lld c=%d", (long long)m, c);
+  if (m <= 0 || c <= 0 || (c & 3)) return fail(UDP_ERR_ARG, "udp_bn_train_fwd: m=%lld c=%d (c must be a multiple of 4)", (long long)m, c);
   if (check_dtype(dtype, "udp_bn_train_fwd")) return UDP_ERR_ARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  UDP_HIP_CHECK(hipMemsetAsync(ws, 0, 2 * (size_t)c * sizeof(double), s));
-  const int rpb = (int)((m + 1023) / 1024 < 32 ? 32 : (m + 1023) / 1024);
-  const unsigned nb = nblocks(m, rpb);
+  const unsigned nb = bn_blocks(m, c);
   UDP_DISPATCH_T(dtype,
-                 (bn_sums_kernel<float, 0><<<nb, 256, 0, s>>>((const float*)x, nullptr, nullptr, nullptr, nullptr, m, c, rpb, ws)),
-                 (bn_sums_kernel<__bf16, 0><<<nb, 256, 0, s>>>((const __bf16*)x, nullptr, nullptr, nullptr, nullptr, m, c, rpb, ws)));
-  bn_fwd_finalize_kernel<<<(c + 255) / 256, 256, 0, s>>>(ws, m, c, eps, momentum, running_mean, running_var, save_mean, save_invstd);
-  const long total = m * c;
+                 (bn_sums_kernel<float, 0><<<nb, 256, 0, s>>>((const float*)x, nullptr, nullptr, nullptr, nullptr, m, c, ws)),
+                 (bn_sums_kernel<__bf16, 0><<<nb, 256, 0, s>>>((const __bf16*)x, nullptr, nullptr, nullptr, nullptr, m, c, ws)));
+  bn_fwd_finalize_kernel<<<(c + 15) / 16, 256, 0, s>>>(ws, (int)nb, m, c, eps, momentum, running_mean, running_var, save_mean, save_invstd);
+  const long total4 = m * c / 4;
   UDP_DISPATCH_T(dtype,
-                 (bn_apply_kernel<float><<<nblocks(total, 256 * 4), 256, 0, s>>>((const float*)x, (const float*)res, save_mean, save_invstd, gamma, beta, total, c, relu, (float*)y)),
-                 (bn_apply_kernel<__bf16><<<nblocks(total, 256 * 4), 256, 0, s>>>((const __bf16*)x, (const __bf16*)res, save_mean, save_invstd, gamma, beta, total, c, relu, (__bf16*)y)));
+                 (bn_apply_kernel<float><<<nblocks(total4, 256 * 2), 256, 0, s>>>((const float*)x, (const float*)res, save_mean, save_invstd, gamma, beta, total4, c, relu, (float*)y)),
+                 (bn_apply_kernel<__bf16><<<nblocks(total4, 256 * 2), 256, 0, s>>>((const __bf16*)x, (const __bf16*)res, save_mean, save_invstd, gamma, beta, total4, c, relu, (__bf16*)y)));
   return launched("udp_bn_train_fwd");
 }
 
@@ -526,21 +630,20 @@ extern "C" int udp_bn_train_bwd(const void* x, const void* dy, const void* y_rel
                                 void* g_out, int dtype, double* ws, void* stream) {
   if (!x || !dy || !gamma || !save_mean || !save_invstd || !dgamma || !dbeta || !dx || !ws)
     return fail(UDP_ERR_ARG, "udp_bn_train_bwd: null pointer");
-  if (m <= 0 || c <= 0) return fail(UDP_ERR_ARG, "udp_bn_train_bwd: m=%lld c=%d", (long long)m, c);
+  if (m <= 0 || c <= 0 || (c & 3)) return fail(UDP_ERR_ARG, "udp_bn_train_bwd: m=%lld c=%d (c must be a multiple of 4)", (long long)m, c);
   if (check_dtype(dtype, "udp_bn_train_bwd")) return UDP_ERR_ARG;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  UDP_HIP_CHECK(hipMemsetAsync(ws, 0, 2 * (size_t)c * sizeof(double), s));
-  const int rpb = (int)((m + 1023) / 1024 < 32 ? 32 : (m + 1023) / 1024);
-  const unsigned nb = nblocks(m, rpb);
+  const unsigned nb = bn_blocks(m, c);
   UDP_DISPATCH_T(dtype,
-                 (bn_sums_kernel<float, 1><<<nb, 256, 0, s>>>((const float*)x, (const float*)dy, (const float*)y_relu, save_mean, save_invstd, m, c, rpb, ws)),
-                 (bn_sums_kernel<__bf16, 1><<<nb, 256, 0, s>>>((const __bf16*)x, (const __bf16*)dy, (const __bf16*)y_relu, save_mean, save_invstd, m, c, rpb, ws)));
-  bn_bwd_finalize_kernel<<<(c + 255) / 256, 256, 0, s>>>(ws, c, dgamma, dbeta);
-  const long total = m * c;
+                 (bn_sums_kernel<float, 1><<<nb, 256, 0, s>>>((const float*)x, (const float*)dy, (const float*)y_relu, save_mean, save_invstd, m, c, ws)),
+                 (bn_sums_kernel<__bf16, 1><<<nb, 256, 0, s>>>((const __bf16*)x, (const __bf16*)dy, (const __bf16*)y_relu, save_mean, save_invstd, m, c, ws)));
+  float* sums = reinterpret_cast<float*>(ws + (size_t)kBnMaxBlocks * 2 * c);      // fp32 {dbeta, dgamma} after the partial rows
+  bn_bwd_finalize_kernel<<<(c + 15) / 16, 256, 0, s>>>(ws, (int)nb, c, dgamma, dbeta, sums);
+  const long total4 = m * c / 4;
   const float inv_m = 1.f / (float)m;
   UDP_DISPATCH_T(dtype,
-                 (bn_bwd_apply_kernel<float><<<nblocks(total, 256 * 4), 256, 0, s>>>((const float*)x, (const float*)dy, (const float*)y_relu, save_mean, save_invstd, gamma, ws, total, c, inv_m, (float*)dx, (float*)g_out)),
-                 (bn_bwd_apply_kernel<__bf16><<<nblocks(total, 256 * 4), 256, 0, s>>>((const __bf16*)x, (const __bf16*)dy, (const __bf16*)y_relu, save_mean, save_invstd, gamma, ws, total, c, inv_m, (__bf16*)dx, (__bf16*)g_out)));
+                 (bn_bwd_apply_kernel<float><<<nblocks(total4, 256 * 2), 256, 0, s>>>((const float*)x, (const float*)dy, (const float*)y_relu, save_mean, save_invstd, gamma, sums, total4, c, inv_m, (float*)dx, (float*)g_out)),
+                 (bn_bwd_apply_kernel<__bf16><<<nblocks(total4, 256 * 2), 256, 0, s>>>((const __bf16*)x, (const __bf16*)dy, (const __bf16*)y_relu, save_mean, save_invstd, gamma, sums, total4, c, inv_m, (__bf16*)dx, (__bf16*)g_out)));
   return launched("udp_bn_train_bwd");
 }
 

@@ -90,7 +90,7 @@ class HRNetTrainer:
             ws_bytes = max(ws_bytes, _lib.lib().udp_conv2d_wgrad_workspace_bytes(cout, cin, ks))
         self._wgrad_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
         self._zeros = torch.zeros(1024, dtype=torch.float32, device=self.device)      # zero bias rows
-        self._bn_ws = torch.empty(2 * 1024, dtype=torch.float64, device=self.device)
+        self._bn_ws = torch.empty(_lib.lib().udp_bn_workspace_doubles(1024), dtype=torch.float64, device=self.device)
         self._loss = torch.zeros(2, dtype=torch.float64, device=self.device)
         self._tape = []
 
