@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UDP_POSE_ABI_VERSION 4
+#define UDP_POSE_ABI_VERSION 5
 
 enum udp_status {
   UDP_OK = 0,
@@ -181,6 +181,20 @@ int udp_gaussian_taps_host(int ksize, float* taps_host);
 int udp_warp_affine(const uint8_t* frame, int fh, int fw, int row_stride_bytes, const double* mats,
                     int n, int oh, int ow, const float* mean3, const float* std3, float* out,
                     void* stream);
+/* Same warp with the training loader's two source transforms folded in: flip_lr = the frame is read
+ * mirrored left-right (data_numpy[:, ::-1, :], JointsDataset.py:218-219; same fixed-point taps),
+ * swap_rb = cv2.COLOR_BGR2RGB (:195-196).  mats: the get_warpmatrix dst->src matrix (:226-227). */
+int udp_warp_affine_ex(const uint8_t* frame, int fh, int fw, int row_stride_bytes, const double* mats,
+                       int n, int oh, int ow, const float* mean3, const float* std3, int flip_lr,
+                       int swap_rb, float* out, void* stream);
+/* AID information dropping (Cutout / HideAndSeek, deep_hrnet/lib/utils/transforms.py:144-224) on
+ * normalized crops img fp32 [n,3,h,w]: dropped pixels become (0-mean)/std.  cutout: fp64
+ * [n,n_patch,4] = (cx, cy, rx, ry) per ellipse (rx <= 0: unused).  hs_grid int32 [n] (0 = off) and
+ * hs_mask uint8 [n,mask_x,mask_y]: cell (i,j) drops rows [i*g,(i+1)*g) for i*g < w and columns
+ * [j*g,(j+1)*g) for j*g < h -- the reference's x/y-swapped indexing (:172-177), kept.  NULL = off. */
+int udp_aid_apply(float* img, int n, int h, int w, const double* cutout, int n_patch,
+                  const int32_t* hs_grid, const uint8_t* hs_mask, int mask_x, int mask_y,
+                  const float* mean3, const float* std3, void* stream);
 /* generate_target (JointsDataset.py:291-385).  joints fp32 [n,j,2] in crop pixels,
  * vis fp32 [n,j].  gaussian: target [n,j,h,w]; offset: [n,3j,h,w].  weight [n,j]. */
 int udp_target_gaussian(const float* joints, const float* vis, int n, int j, int img_w, int img_h,

@@ -15,7 +15,7 @@ UDP_F32, UDP_BF16 = 0, 1
 UDP_OP_STEM, UDP_OP_CONV, UDP_OP_FUSE, UDP_OP_STEM7, UDP_OP_MAXPOOL, UDP_OP_BILINEAR = 0, 1, 2, 3, 4, 5
 UDP_OP_PSA_POOL, UDP_OP_PSA_MLP, UDP_OP_PSA_SCALE, UDP_OP_PSA_SP = 6, 7, 8, 9
 UDP_BUF_NONE, UDP_BUF_OUTPUT = -1, -2
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_LANES, MAX_WAIT = 4, 8
 
 
@@ -62,6 +62,10 @@ _SIGS = {
     "udp_gaussian_taps_host": (C.c_int, [C.c_int, C.POINTER(C.c_float)]),
     "udp_warp_affine": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int,
                                   C.POINTER(C.c_float), C.POINTER(C.c_float), _P, _P]),
+    "udp_warp_affine_ex": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int,
+                                     C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int, _P, _P]),
+    "udp_aid_apply": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, _P, C.c_int, C.c_int,
+                                C.POINTER(C.c_float), C.POINTER(C.c_float), _P]),
     "udp_target_gaussian": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_float, _P, _P, _P]),
     "udp_target_offset": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -17,7 +17,7 @@ namespace udp {
 __global__ __launch_bounds__(256) void warp_affine_kernel(const uint8_t* __restrict__ frame, int fh, int fw,
                                                           int row_stride, const double* __restrict__ mats,
                                                           int n, int oh, int ow, float m0, float m1, float m2,
-                                                          float s0, float s1, float s2,
+                                                          float s0, float s1, float s2, int flip_lr, int swap_rb,
                                                           float* __restrict__ out) {
   const long total = (long)n * oh * ow;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -39,16 +39,54 @@ __global__ __launch_bounds__(256) void warp_affine_kernel(const uint8_t* __restr
     const bool y0ok = sy >= 0 && sy < fh, y1ok = sy + 1 >= 0 && sy + 1 < fh;
     const uint8_t* r0 = frame + (y0ok ? sy : 0) * (long)row_stride;
     const uint8_t* r1 = frame + (y1ok ? sy + 1 : 0) * (long)row_stride;
-    const long c0 = (x0ok ? sx : 0) * 3, c1 = (x1ok ? sx + 1 : 0) * 3;
+    // flip_lr: the source is the frame mirrored left-right (data_numpy[:, ::-1, :], JointsDataset.py:219):
+    // same fixed-point taps, columns looked up mirrored
+    const long c0 = (x0ok ? (flip_lr ? fw - 1 - sx : sx) : 0) * 3, c1 = (x1ok ? (flip_lr ? fw - 2 - sx : sx + 1) : 0) * 3;
     const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const int p00 = (y0ok && x0ok) ? r0[c0 + c] : 0, p01 = (y0ok && x1ok) ? r0[c1 + c] : 0;
-      const int p10 = (y1ok && x0ok) ? r1[c0 + c] : 0, p11 = (y1ok && x1ok) ? r1[c1 + c] : 0;
+      const int sc = swap_rb ? 2 - c : c;      // cv2.COLOR_BGR2RGB (:195-196)
+      const int p00 = (y0ok && x0ok) ? r0[c0 + sc] : 0, p01 = (y0ok && x1ok) ? r0[c1 + sc] : 0;
+      const int p10 = (y1ok && x0ok) ? r1[c0 + sc] : 0, p11 = (y1ok && x1ok) ? r1[c1 + sc] : 0;
       int v = (w00 * p00 + w01 * p01 + w10 * p10 + w11 * p11 + 16384) >> 15;
       v = v < 0 ? 0 : (v > 255 ? 255 : v);
       const float f = (float)v / 255.0f;
       out[(((long)b * 3 + c) * oh + y) * ow + x] = (f - mean[c]) / stdv[c];
+    }
+  }
+}
+
+// AID information dropping on the normalized crop (lib/utils/transforms.py:144-224): a dropped pixel is
+// uint8 0 before ToTensor/Normalize, i.e. (0 - mean)/std here.
+//   Cutout: ((cx - x)/rx)^2 + ((cy - y)/ry)^2 <= 1 in fp64, `P` ellipses per image (rx <= 0: unused slot)
+//   HideAndSeek: grid g; the reference indexes img[x:x_end, y:y_end] with x stepping over the WIDTH and y
+//   over the HEIGHT (:172-177) -- rows are cut by the x cells, columns by the y cells; kept as is.
+__global__ __launch_bounds__(256) void aid_apply_kernel(float* __restrict__ img, int n, int h, int w,
+                                                        const double* __restrict__ cutout, int P,
+                                                        const int32_t* __restrict__ hs_grid,
+                                                        const uint8_t* __restrict__ hs_mask, int mx, int my,
+                                                        float d0, float d1, float d2) {
+  const long total = (long)n * h * w;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int x = i % w;
+    const long t = i / w;
+    const int y = t % h;
+    const int b = t / h;
+    bool drop = false;
+    for (int k = 0; k < P && !drop; ++k) {
+      const double* e = cutout + ((long)b * P + k) * 4;
+      if (e[2] > 0.0) {
+        const double xo = (e[0] - (double)x) / e[2], yo = (e[1] - (double)y) / e[3];
+        drop = xo * xo + yo * yo <= 1.0;
+      }
+    }
+    const int g = hs_grid ? hs_grid[b] : 0;
+    if (!drop && g > 0 && y < w && x < h) drop = hs_mask[((long)b * mx + y / g) * my + x / g] != 0;
+    if (drop) {
+      float* o = img + (long)b * 3 * h * w + (long)y * w + x;
+      o[0] = d0;
+      o[(long)h * w] = d1;
+      o[2L * h * w] = d2;
     }
   }
 }
@@ -176,16 +214,36 @@ static unsigned grid_for(long total) {
 
 using namespace udp;
 
-extern "C" int udp_warp_affine(const uint8_t* frame, int fh, int fw, int row_stride_bytes, const double* mats,
-                               int n, int oh, int ow, const float* mean3, const float* std3, float* out,
-                               void* stream) {
+extern "C" int udp_warp_affine_ex(const uint8_t* frame, int fh, int fw, int row_stride_bytes, const double* mats,
+                                  int n, int oh, int ow, const float* mean3, const float* std3, int flip_lr,
+                                  int swap_rb, float* out, void* stream) {
   if (!frame || !mats || !mean3 || !std3 || !out) return fail(UDP_ERR_ARG, "udp_warp_affine: null pointer");
   if (fh <= 0 || fw <= 0 || row_stride_bytes < fw * 3 || n < 0 || oh <= 0 || ow <= 0)
     return fail(UDP_ERR_ARG, "udp_warp_affine: bad shape");
   if (n == 0) return UDP_OK;
   hipLaunchKernelGGL(warp_affine_kernel, dim3(grid_for((long)n * oh * ow)), dim3(256), 0, (hipStream_t)stream,
                      frame, fh, fw, row_stride_bytes, mats, n, oh, ow, mean3[0], mean3[1], mean3[2], std3[0],
-                     std3[1], std3[2], out);
+                     std3[1], std3[2], flip_lr ? 1 : 0, swap_rb ? 1 : 0, out);
+  UDP_HIP_CHECK(hipGetLastError());
+  return UDP_OK;
+}
+
+extern "C" int udp_warp_affine(const uint8_t* frame, int fh, int fw, int row_stride_bytes, const double* mats,
+                               int n, int oh, int ow, const float* mean3, const float* std3, float* out,
+                               void* stream) {
+  return udp_warp_affine_ex(frame, fh, fw, row_stride_bytes, mats, n, oh, ow, mean3, std3, 0, 0, out, stream);
+}
+
+extern "C" int udp_aid_apply(float* img, int n, int h, int w, const double* cutout, int n_patch, const int32_t* hs_grid,
+                             const uint8_t* hs_mask, int mask_x, int mask_y, const float* mean3, const float* std3,
+                             void* stream) {
+  if (!img || !mean3 || !std3) return fail(UDP_ERR_ARG, "udp_aid_apply: null pointer");
+  if (n < 0 || h <= 0 || w <= 0 || n_patch < 0 || (n_patch > 0 && !cutout)) return fail(UDP_ERR_ARG, "udp_aid_apply: bad shape");
+  if (hs_grid && (!hs_mask || mask_x <= 0 || mask_y <= 0)) return fail(UDP_ERR_ARG, "udp_aid_apply: hide-and-seek mask missing");
+  if (n == 0) return UDP_OK;
+  hipLaunchKernelGGL(aid_apply_kernel, dim3(grid_for((long)n * h * w)), dim3(256), 0, (hipStream_t)stream, img, n, h, w,
+                     cutout, n_patch, hs_grid, hs_mask, mask_x, mask_y, (0.f - mean3[0]) / std3[0],
+                     (0.f - mean3[1]) / std3[1], (0.f - mean3[2]) / std3[2]);
   UDP_HIP_CHECK(hipGetLastError());
   return UDP_OK;
 }

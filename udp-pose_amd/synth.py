@@ -346,3 +346,34 @@ def synth_rsn18_state_dict(out_channels=17, seed=0, bn_calib=None):
             for k in ("stage0.upsample.up4.res_conv2.bn.weight", "stage0.upsample.up4.res_conv2.bn.bias"):
                 sd[k] = sd[k] * f
     return sd
+
+
+COCO_FLIP_PAIRS = [[1, 2], [3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]]     # lib/dataset/coco.py:91-92
+COCO_UPPER_BODY = (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10)                                              # coco.py:94
+
+
+def synth_db(n=8, seed=77):
+    """Synthetic dataset records shaped like COCODataset's db entries (coco.py:150-200): joints_3d,
+    joints_3d_vis, center, scale (+ the size / seed of the synthetic frame that stands for the image)."""
+    rng = np.random.default_rng(seed)
+    db = []
+    for i in range(n):
+        h, w = (480, 640) if i % 2 == 0 else (427, 640)
+        joints = np.zeros((17, 3), np.float32)
+        vis = np.zeros((17, 3), np.float32)
+        cx, cy = rng.uniform(150, w - 150), rng.uniform(120, h - 120)
+        joints[:, 0] = cx + rng.normal(0, 45, 17)
+        joints[:, 1] = cy + rng.normal(0, 80, 17)
+        v = (rng.random(17) < (0.9 if i % 3 else 0.45)).astype(np.float32)
+        vis[:, 0] = vis[:, 1] = v
+        joints[:, :2] *= v[:, None]
+        bw, bh = rng.uniform(80, 220), rng.uniform(150, 330)
+        if bw > 0.75 * bh:
+            bh = bw / 0.75
+        else:
+            bw = bh * 0.75
+        db.append({"image": "frame_%d" % i, "joints_3d": joints, "joints_3d_vis": vis,
+                   "center": np.array([cx, cy], np.float32),
+                   "scale": np.array([bw / 200 * 1.25, bh / 200 * 1.25], np.float32),
+                   "frame_hw": (h, w), "frame_seed": 500 + i})
+    return db
