@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UDP_POSE_ABI_VERSION 5
+#define UDP_POSE_ABI_VERSION 6
 
 enum udp_status {
   UDP_OK = 0,
@@ -210,6 +210,22 @@ int udp_target_offset(const float* joints, const float* vis, int n, int j, int i
  * ------------------------------------------------------------------------- */
 int udp_mse_loss(const float* pred, const float* target, const float* weight, int b, int j, int hw,
                  int is_offset, double* loss_out, float* grad, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Keypoint rescoring + OKS-NMS: deep_hrnet/lib/dataset/coco.py:321-356 with
+ * oks_iou / oks_nms of deep_hrnet/lib/nms/nms.py:75-124, all images in one launch.
+ * Persons of image i are rows img_offsets[i] .. img_offsets[i+1] (both a device and a host copy of the
+ * int32 [n_images+1] offsets are passed; at most 1024 persons per image).  kpts fp32 [P,J,3] (x, y,
+ * score) in image pixels, areas / box_scores fp64 [P], vars fp64 [J] = (2*sigma_j)^2.
+ * rescore != 0: score = mean(joint scores > in_vis_thre) * box_score (coco.py:326-341), else box_score.
+ * use_vis != 0 reproduces oks_iou's in_vis_thre branch (only joints of the candidate above
+ * oks_vis_thre count).  scores_out fp64 [P]; keep_rank int32 [P]: position in the keep list (selection
+ * order = descending score) or -1 when suppressed (overlap > oks_thre with a kept pose).
+ * ------------------------------------------------------------------------- */
+int udp_oks_nms(const float* kpts, const double* areas, const double* box_scores,
+                const int32_t* img_offsets, const int32_t* img_offsets_host, int n_images, int num_joints,
+                const double* vars_dev, double in_vis_thre, int rescore, double oks_thre, int use_vis,
+                double oks_vis_thre, double* scores_out, int32_t* keep_rank, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Training step (deep_hrnet/lib/core/function.py:38-77: model.train(), forward,

@@ -377,3 +377,28 @@ def synth_db(n=8, seed=77):
                    "scale": np.array([bw / 200 * 1.25, bh / 200 * 1.25], np.float32),
                    "frame_hw": (h, w), "frame_seed": 500 + i})
     return db
+
+
+def synth_person_sets(n_images, seed=0, num_joints=17):
+    """Detections for OKS-NMS: per image a few distinct poses, each with near-duplicates (jittered copies).
+    Returns kpts fp32 [P, J, 3] (x, y, score), areas fp64 [P], box scores fp64 [P], image offsets int32 [I+1]."""
+    rng = np.random.default_rng(seed)
+    kpts, areas, scores, offs = [], [], [], [0]
+    for _ in range(n_images):
+        n_pose = int(rng.integers(1, 5))
+        for _p in range(n_pose):
+            base = np.zeros((num_joints, 3), np.float32)
+            cx, cy, sc = rng.uniform(100, 500), rng.uniform(100, 380), rng.uniform(40, 120)
+            base[:, 0] = cx + rng.normal(0, sc / 3, num_joints)
+            base[:, 1] = cy + rng.normal(0, sc, num_joints)
+            area = float((2 * sc) * (3 * sc))
+            for _d in range(int(rng.integers(1, 5))):
+                k = base.copy()
+                jit = rng.choice([0.5, 3.0, 12.0])
+                k[:, :2] += rng.normal(0, jit, (num_joints, 2)).astype(np.float32)
+                k[:, 2] = rng.uniform(0.05, 0.95, num_joints).astype(np.float32)
+                kpts.append(k)
+                areas.append(area * rng.uniform(0.9, 1.1))
+                scores.append(float(rng.uniform(0.3, 1.0)))
+        offs.append(len(kpts))
+    return (np.stack(kpts), np.array(areas, np.float64), np.array(scores, np.float64), np.array(offs, np.int32))
