@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UDP_POSE_ABI_VERSION 6
+#define UDP_POSE_ABI_VERSION 7
 
 enum udp_status {
   UDP_OK = 0,
@@ -241,6 +241,15 @@ int udp_oks_nms(const float* kpts, const double* areas, const double* box_scores
  *   udp_conv2d_fused(dy, w_dgrad); for stride 2 apply it to udp_zero_stuff2(dy). */
 int udp_pack_conv_weights(const float* w, int cout, int cin, int ks, int dtype, void* w_fwd,
                           void* w_dgrad, void* stream);
+/* The same for every conv of a model in one launch: a device array of n descriptors (shapes are
+ * validated by the host that builds the table; ks in {1,3}). */
+typedef struct udp_pack_desc {
+  const float* w;
+  void* w_fwd;
+  void* w_dgrad; /* may be NULL */
+  int32_t cout, cin, ks, reserved;
+} udp_pack_desc;
+int udp_pack_conv_weights_batch(const udp_pack_desc* descs_dev, int n, int dtype, void* stream);
 /* out[n][2y][2x][c] = dy[n][y][x][c], zero elsewhere (out: [n][2h][2w][c]). */
 int udp_zero_stuff2(const void* dy, int n, int h, int w, int c, int dtype, void* out, void* stream);
 /* dW[co][ci][ky][kx] (+)= sum_{n,y,x} dy[n,y,x,co] * x[n, y*s+ky-ks/2, x*s+kx-ks/2, ci]
@@ -255,7 +264,8 @@ int udp_conv2d_wgrad(const void* x, const void* dy, int n, int hin, int win, int
  * running_mean/var <- (1-momentum)*running + momentum*batch (unbiased variance), either may be NULL;
  * y = [relu](xhat*gamma + beta [+ res]).  save_mean / save_invstd fp32 [c] feed the backward.
  * c must be a multiple of 4.  ws: udp_bn_workspace_doubles(c) doubles of scratch (per-block partial
- * sums, summed in a fixed order: results are run-to-run deterministic). */
+ * sums, summed in a fixed order: results are run-to-run deterministic).  A workspace serves one
+ * stream at a time. */
 size_t udp_bn_workspace_doubles(int c);
 int udp_bn_train_fwd(const void* x, int64_t m, int c, const float* gamma, const float* beta, float eps,
                      float momentum, float* running_mean, float* running_var, float* save_mean,

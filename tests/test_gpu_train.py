@@ -128,7 +128,7 @@ def test_batchnorm_train_forward_backward(c, h, w, n, relu, with_res):
     resd = _nhwc(res.detach(), c) if with_res else None
     gd, bd, rmd, rvd = gamma.detach().cuda(), beta.detach().cuda(), rm.cuda(), rv.cuda()
     save = torch.empty(2 * c, device="cuda")
-    ws = torch.empty(L.udp_bn_workspace_doubles(c), dtype=torch.float64, device="cuda")
+    ws = torch.zeros(L.udp_bn_workspace_doubles(c), dtype=torch.float64, device="cuda")
     yd = torch.empty_like(xd)
     _lib.check(L.udp_bn_train_fwd(xd.data_ptr(), m, c, gd.data_ptr(), bd.data_ptr(), 1e-5, 0.1, rmd.data_ptr(),
                                   rvd.data_ptr(), save.data_ptr(), save.data_ptr() + 4 * c,

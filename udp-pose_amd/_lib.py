@@ -15,7 +15,7 @@ UDP_F32, UDP_BF16 = 0, 1
 UDP_OP_STEM, UDP_OP_CONV, UDP_OP_FUSE, UDP_OP_STEM7, UDP_OP_MAXPOOL, UDP_OP_BILINEAR = 0, 1, 2, 3, 4, 5
 UDP_OP_PSA_POOL, UDP_OP_PSA_MLP, UDP_OP_PSA_SCALE, UDP_OP_PSA_SP = 6, 7, 8, 9
 UDP_BUF_NONE, UDP_BUF_OUTPUT = -1, -2
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_LANES, MAX_WAIT = 4, 8
 
 
@@ -38,6 +38,12 @@ class UdpPoseError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("udp_pose_hip error %d: %s" % (code, msg))
         self.code = code
+
+
+class PackDesc(C.Structure):
+    """struct udp_pack_desc."""
+    _fields_ = [("w", C.c_void_p), ("w_fwd", C.c_void_p), ("w_dgrad", C.c_void_p),
+                ("cout", C.c_int32), ("cin", C.c_int32), ("ks", C.c_int32), ("reserved", C.c_int32)]
 
 
 _P = C.c_void_p
@@ -75,6 +81,7 @@ _SIGS = {
                               C.c_double, C.c_int, C.c_double, _P, _P, _P]),
     # training step
     "udp_pack_conv_weights": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "udp_pack_conv_weights_batch": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "udp_zero_stuff2": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "udp_conv2d_wgrad_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "udp_conv2d_wgrad": (C.c_int, [_P, _P] + [C.c_int] * 12 + [_P, C.c_int, _P, C.c_size_t, _P]),

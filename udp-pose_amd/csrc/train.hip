@@ -61,6 +61,29 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int cout, int c
   }
 }
 
+// all layers of a model in one launch: blockIdx.y = layer (descriptor table in device memory)
+template <typename T>
+__global__ void pack_weights_batch_kernel(const udp_pack_desc* __restrict__ descs) {
+  const udp_pack_desc d = descs[blockIdx.y];
+  const int taps = d.ks * d.ks, cout = d.cout, cin = d.cin;
+  const int cout_pad = (cout + 31) / 32 * 32, cin_k = (cin + 15) / 16 * 16, cin_pad = (cin + 31) / 32 * 32, cout_k = (cout + 15) / 16 * 16;
+  const float* w = d.w;
+  T* fwd = reinterpret_cast<T*>(d.w_fwd);
+  T* dg = reinterpret_cast<T*>(d.w_dgrad);
+  const long nf = (long)taps * cout_pad * cin_k;
+  const long nd = dg ? (long)taps * cin_pad * cout_k : 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nf + nd; i += (long)gridDim.x * blockDim.x) {
+    if (i < nf) {
+      const int ci = i % cin_k, co = (i / cin_k) % cout_pad, t = i / ((long)cin_k * cout_pad);
+      fwd[i] = fromf<T>((co < cout && ci < cin) ? w[((long)co * cin + ci) * taps + t] : 0.f);
+    } else {
+      const long k = i - nf;
+      const int co = k % cout_k, ci = (k / cout_k) % cin_pad, t = k / ((long)cout_k * cin_pad);
+      dg[k] = fromf<T>((co < cout && ci < cin) ? w[((long)co * cin + ci) * taps + (taps - 1 - t)] : 0.f);
+    }
+  }
+}
+
 // out[n][2y][2x][c] = in[n][y][x][c], zeros elsewhere
 template <typename T>
 __global__ void zero_stuff2_kernel(const T* __restrict__ in, long total_out, int h, int w, int c, T* __restrict__ out) {
@@ -522,6 +545,16 @@ extern "C" int udp_pack_conv_weights(const float* w, int cout, int cin, int ks, 
                  (pack_weights_kernel<__bf16><<<nblocks(total, 256, 4096), 256, 0, s>>>(
                      w, cout, cin, ks, cout_pad, cin_k, cin_pad, cout_k, (__bf16*)w_fwd, (__bf16*)w_dgrad)));
   return launched("udp_pack_conv_weights");
+}
+
+extern "C" int udp_pack_conv_weights_batch(const udp_pack_desc* descs_dev, int n, int dtype, void* stream) {
+  if (!descs_dev || n <= 0) return fail(UDP_ERR_ARG, "udp_pack_conv_weights_batch: argument");
+  if (check_dtype(dtype, "udp_pack_conv_weights_batch")) return UDP_ERR_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid(64, n);
+  UDP_DISPATCH_T(dtype, (pack_weights_batch_kernel<float><<<grid, 256, 0, s>>>(descs_dev)),
+                 (pack_weights_batch_kernel<__bf16><<<grid, 256, 0, s>>>(descs_dev)));
+  return launched("udp_pack_conv_weights_batch");
 }
 
 extern "C" int udp_zero_stuff2(const void* dy, int n, int h, int w, int c, int dtype, void* out, void* stream) {

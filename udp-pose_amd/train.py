@@ -89,8 +89,14 @@ class HRNetTrainer:
             self._convs[k[:-len(".weight")]] = (cout, cin, ks, fwd, dg)
             ws_bytes = max(ws_bytes, _lib.lib().udp_conv2d_wgrad_workspace_bytes(cout, cin, ks))
         self._wgrad_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
+        descs = (_lib.PackDesc * len(self._convs))()
+        for i, (name, (cout, cin, ks, fwd, dg)) in enumerate(self._convs.items()):
+            descs[i].w, descs[i].w_fwd = self._p(name + ".weight"), fwd.data_ptr()
+            descs[i].w_dgrad = None if dg is None else dg.data_ptr()
+            descs[i].cout, descs[i].cin, descs[i].ks = cout, cin, ks
+        self._pack_table = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(self.device)
         self._zeros = torch.zeros(1024, dtype=torch.float32, device=self.device)      # zero bias rows
-        self._bn_ws = torch.empty(_lib.lib().udp_bn_workspace_doubles(1024), dtype=torch.float64, device=self.device)
+        self._bn_ws = torch.zeros(_lib.lib().udp_bn_workspace_doubles(1024), dtype=torch.float64, device=self.device)
         self._loss = torch.zeros(2, dtype=torch.float64, device=self.device)
         self._tape = []
 
@@ -310,9 +316,7 @@ class HRNetTrainer:
         if h % 32 or w % 32:
             raise ValueError("input %dx%d must be a multiple of 32" % (h, w))
         self._tape = []
-        for name, (cout, cin, ks, wf, wd) in self._convs.items():
-            _lib.check(L.udp_pack_conv_weights(self._p(name + ".weight"), cout, cin, ks, self._dt, wf.data_ptr(),
-                                               None if wd is None else wd.data_ptr(), self._stream()))
+        _lib.check(L.udp_pack_conv_weights_batch(self._pack_table.data_ptr(), len(self._convs), self._dt, self._stream()))
         a = self._new(n, h, w, 3, needs_grad=False)
         _lib.check(L.udp_nchw_to_nhwc(x.data_ptr(), n, 3, h, w, a.ck, a.buf.data_ptr(), self._dt, self._stream()))
         a = self._bn(self._conv(a, "conv1", stride=2), "bn1")
