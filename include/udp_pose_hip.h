@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UDP_POSE_ABI_VERSION 7
+#define UDP_POSE_ABI_VERSION 8
 
 enum udp_status {
   UDP_OK = 0,
@@ -292,9 +292,10 @@ int udp_bias_grad(const void* g, int64_t m, int c_pitch, int c, float* db, int d
 /* NCHW fp32 [n,c,h,w] -> NHWC `dtype` [n,h,w,c_pad], channels c..c_pad zero. */
 int udp_nchw_to_nhwc(const float* src, int n, int c, int h, int w, int c_pad, void* dst, int dtype,
                      void* stream);
-/* torch.optim.Adam (no weight decay, no amsgrad) over flat fp32 buffers; step counts from 1. */
+/* torch.optim.Adam (no weight decay, no amsgrad) over flat fp32 buffers; step counts from 1.
+ * The gradient is read as g*grad_scale (1/world_size after a SUM all-reduce; 1 otherwise). */
 int udp_adam_step(float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1,
-                  float beta2, float eps, int step, void* stream);
+                  float beta2, float eps, int step, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from udp_pose_amd.dist import allreduce_mean_, gather_keypoints, shard_bounds
+from udp_pose_amd.dist import allreduce_mean_, allreduce_sum_, gather_keypoints, shard_bounds
 
 
 def test_shard_bounds_cover_everything():
@@ -45,6 +45,9 @@ def _worker(rank, world, port, n_total, q):
         g = torch.full((1000,), float(rank + 1))
         allreduce_mean_(g, bucket_elems=300)
         ok_reduce = bool(torch.allclose(g, torch.full((1000,), (1 + world) / 2.0)))
+        g = torch.full((1000,), float(rank + 1))
+        allreduce_sum_(g, bucket_elems=256)
+        ok_reduce &= bool(torch.equal(g, torch.full((1000,), float(sum(range(1, world + 1))))))
         q.put((rank, ok_gather, ok_reduce))
     finally:
         dist.destroy_process_group()

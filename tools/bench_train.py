@@ -15,24 +15,40 @@ ap.add_argument("--warmup", type=int, default=2)
 ap.add_argument("--dtype", default="f32")
 ap.add_argument("--target", default="gaussian")
 a = ap.parse_args()
+# one process per GPU under torch.distributed.run (backend nccl = RCCL); plain `python` = one GPU
+world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+if world > 1:
+    import torch.distributed as dist
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group("nccl", rank=rank, world_size=world)
 nj = 17
 sd = synth.synth_state_dict(synth.W32_EXTRA, nj, a.target, seed=0)
 tr = HRNetTrainer({"MODEL": {"EXTRA": synth.W32_EXTRA, "NUM_JOINTS": nj, "TARGET_TYPE": a.target}}, sd, dtype=a.dtype)
-x = torch.from_numpy(synth.synth_crops(a.batch, 256, 192, seed=1)).cuda()
+x = torch.from_numpy(synth.synth_crops(a.batch, 256, 192, seed=1 + rank)).cuda()
 c = nj * (3 if a.target == "offset" else 1)
 tg = torch.from_numpy(synth.synth_heatmaps(a.batch, nj, 64, 48, seed=2, channels_per_joint=c // nj)).cuda()
 tw = torch.ones(a.batch, nj, 1, device="cuda")
 for _ in range(a.warmup):
-    loss = tr.train_step(x, tg, tw)
+    loss = tr.train_step(x, tg, tw, world_size=world)
 torch.cuda.synchronize()
+if world > 1:
+    dist.barrier()
 t0 = time.time()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(a.steps):
-    loss = tr.train_step(x, tg, tw)
+    loss = tr.train_step(x, tg, tw, world_size=world)
 e1.record()
 torch.cuda.synchronize()
 wall = (time.time() - t0) / a.steps * 1e3
 dev = e0.elapsed_time(e1) / a.steps
-print("train W32 b=%d %s: %.1f ms/step (device %.1f ms), %.0f img/s, loss %s, peak mem %.1f GiB" % (
-    a.batch, a.dtype, wall, dev, a.batch / wall * 1e3, loss.cpu().numpy(), torch.cuda.max_memory_allocated() / 2**30))
+if world > 1:
+    t = torch.tensor([wall], device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall = float(t.item())
+    dist.barrier()
+    dist.destroy_process_group()
+if rank == 0:
+    print("world %d (global batch %d): %.0f img/s" % (world, a.batch * world, a.batch * world / wall * 1e3))
+    print("train W32 b=%d/GPU %s: %.1f ms/step (device %.1f ms), %.0f img/s per GPU, loss %s, peak mem %.1f GiB" % (
+        a.batch, a.dtype, wall, dev, a.batch / wall * 1e3, loss.cpu().numpy(), torch.cuda.max_memory_allocated() / 2**30))

@@ -15,7 +15,7 @@ UDP_F32, UDP_BF16 = 0, 1
 UDP_OP_STEM, UDP_OP_CONV, UDP_OP_FUSE, UDP_OP_STEM7, UDP_OP_MAXPOOL, UDP_OP_BILINEAR = 0, 1, 2, 3, 4, 5
 UDP_OP_PSA_POOL, UDP_OP_PSA_MLP, UDP_OP_PSA_SCALE, UDP_OP_PSA_SP = 6, 7, 8, 9
 UDP_BUF_NONE, UDP_BUF_OUTPUT = -1, -2
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_LANES, MAX_WAIT = 4, 8
 
 
@@ -95,7 +95,8 @@ _SIGS = {
     "udp_upsample_bwd": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P]),
     "udp_bias_grad": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, _P, C.c_int, _P]),
     "udp_nchw_to_nhwc": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
-    "udp_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, _P]),
+    "udp_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
+                                C.c_float, _P]),
 }
 EXPORTS = tuple(_SIGS)
 

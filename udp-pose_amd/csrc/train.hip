@@ -490,9 +490,9 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
 // torch.optim.Adam single-tensor rule (betas, eps; no weight decay, no amsgrad): lib/utils/utils.py:70-74
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long count, float b1, float b2, float eps,
-                                                   float step_size, float inv_sqrt_bc2) {
+                                                   float step_size, float inv_sqrt_bc2, float grad_scale) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) {
-    const float gi = g[i];
+    const float gi = grad_scale == 1.f ? g[i] : g[i] * grad_scale;
     const float mi = b1 * m[i] + (1.f - b1) * gi;
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
     m[i] = mi;
@@ -612,7 +612,8 @@ extern "C" int udp_conv2d_wgrad(const void* x, const void* dy, int n, int hin, i
   p.tiles_ci = (cin + 31) / 32;
   const int tiles = p.tiles_ci * ((cout + 31) / 32);
   const size_t per = (size_t)ks * ks * cout * cin * sizeof(float);
-  int splits = (1024 + tiles - 1) / tiles;                 // aim at >= 1024 workgroups
+  static const int target_wgs = getenv("UDP_POSE_WGRAD_WGS") ? atoi(getenv("UDP_POSE_WGRAD_WGS")) : 1024;
+  int splits = (target_wgs + tiles - 1) / tiles;           // aim at >= 1024 workgroups (4 per CU)
   if (splits > p.units) splits = p.units;
   if ((size_t)splits * per > workspace_bytes) splits = (int)(workspace_bytes / per);
   if (splits < 1) return fail(UDP_ERR_ARG, "udp_conv2d_wgrad: workspace of %zu bytes is smaller than one partial (%zu)", workspace_bytes, per);
@@ -735,11 +736,11 @@ extern "C" int udp_nchw_to_nhwc(const float* src, int n, int c, int h, int w, in
 }
 
 extern "C" int udp_adam_step(float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1, float beta2,
-                             float eps, int step, void* stream) {
+                             float eps, int step, float grad_scale, void* stream) {
   if (!p || !g || !m || !v || count <= 0 || step < 1) return fail(UDP_ERR_ARG, "udp_adam_step: argument");
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   adam_kernel<<<nblocks(count, 256 * 4), 256, 0, s>>>(p, g, m, v, count, beta1, beta2, eps, (float)((double)lr / bc1),
-                                                       (float)(1.0 / sqrt(bc2)));
+                                                       (float)(1.0 / sqrt(bc2)), grad_scale);
   return launched("udp_adam_step");
 }

@@ -45,6 +45,17 @@ def gather_keypoints(local, n_total, group=None):
     return torch.cat(out, dim=0)
 
 
+def allreduce_sum_(flat_grads, bucket_elems=6 * 1024 * 1024, group=None):
+    """In-place SUM over ranks of a flat gradient buffer, in ~25 MB buckets issued back to back (xGMI is
+    point-to-point: several buckets in flight keep every link busy).  The 1/world_size of the mean is
+    applied by the consumer (udp_adam_step's grad_scale): no arithmetic outside RCCL and our kernels."""
+    works = [dist.all_reduce(flat_grads[lo:lo + bucket_elems], op=dist.ReduceOp.SUM, group=group, async_op=True)
+             for lo in range(0, flat_grads.numel(), bucket_elems)]
+    for w in works:
+        w.wait()
+    return works
+
+
 def allreduce_mean_(flat_grads, bucket_elems=6 * 1024 * 1024, group=None):
     """In-place mean over ranks of a flat gradient buffer, in buckets (xGMI is point-to-point:
     ~25 MB fp32 buckets keep every link busy and let later buckets overlap remaining backward work).

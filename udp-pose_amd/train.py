@@ -359,12 +359,14 @@ class HRNetTrainer:
                                            self._stream()))
         return self._loss, d
 
-    def adam_step(self):
-        """optimizer.step(): torch.optim.Adam(lr) on the flat parameter buffer (utils.py:70-74)."""
+    def adam_step(self, grad_scale=1.0):
+        """optimizer.step(): torch.optim.Adam(lr) on the flat parameter buffer (utils.py:70-74).
+        ``grad_scale``: 1/world_size after the SUM all-reduce of the gradient."""
         self.step_count += 1
         _lib.check(_lib.lib().udp_adam_step(self.flat.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(),
                                             self.exp_avg_sq.data_ptr(), self._n_param, self.lr, self.betas[0],
-                                            self.betas[1], self.eps, self.step_count, self._stream()))
+                                            self.betas[1], self.eps, self.step_count, float(grad_scale),
+                                            self._stream()))
 
     def train_step(self, x, target, target_weight, world_size=1):
         """function.py:46-76 for one batch.  Returns the loss tensor fp64 [2] = (L_hm, L_offset) on device."""
@@ -372,7 +374,7 @@ class HRNetTrainer:
         loss, d = self.loss_and_grad(heat, target.contiguous(), target_weight.contiguous())
         self.backward(d)
         if world_size > 1:
-            from .dist import allreduce_mean_
-            allreduce_mean_(self.grad)
-        self.adam_step()
+            from .dist import allreduce_sum_
+            allreduce_sum_(self.grad)                      # the one exchange step; mean = grad_scale
+        self.adam_step(1.0 / world_size)
         return loss
