@@ -292,3 +292,28 @@ def test_bf16_storage_training_tracks_fp32_and_learns():
     vals = np.array(list(cos.values()))
     print("bf16-vs-fp32 gradient cosine: min %.3f (%s) median %.4f" % (vals.min(), min(cos, key=cos.get), np.median(vals)))
     assert vals.min() > 0.8 and np.median(vals) > 0.97, (vals.min(), np.median(vals))
+
+
+@pytest.mark.parametrize("ks,stride,cin,cout,h,w,n", [
+    (3, 1, 32, 32, 64, 48, 3), (3, 2, 32, 64, 32, 24, 2), (1, 1, 64, 256, 16, 12, 2), (1, 1, 128, 17, 32, 24, 2),
+    (3, 2, 3, 64, 64, 32, 2), (3, 1, 256, 256, 8, 6, 5), (3, 1, 48, 48, 12, 9, 2), (3, 1, 64, 64, 96, 72, 1),
+    (3, 2, 64, 64, 128, 96, 1), (3, 1, 16, 16, 24, 16, 4)])
+def test_conv_weight_gradient_bf16_mfma(ks, stride, cin, cout, h, w, n):
+    """wgrad_bf16_kernel (bf16 MFMA through transposed LDS reads) vs autograd on the bf16-rounded operands:
+    products of bf16 numbers are exact in fp32, so only the fp32 summation order differs."""
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(ks * 100 + cin + cout + h + 1)
+    x = torch.randn(n, cin, h, w, generator=g).to(torch.bfloat16).float()
+    wt = (torch.randn(cout, cin, ks, ks, generator=g) / np.sqrt(cin * ks * ks)).requires_grad_(True)
+    y = F.conv2d(x, wt, stride=stride, padding=ks // 2)
+    dy = torch.randn(y.shape, generator=g).to(torch.bfloat16).float()
+    y.backward(dy)
+    ho, wo = y.shape[2:]
+    cin_k, cout_k = _rup(cin, 16), _rup(cout, 16)
+    xd, dyd = _nhwc(x, cin_k).to(torch.bfloat16), _nhwc(dy, cout_k).to(torch.bfloat16)
+    dw = torch.full((cout, cin, ks, ks), 7.0, device="cuda")
+    ws = torch.empty(L.udp_conv2d_wgrad_workspace_bytes(cout, cin, ks), dtype=torch.uint8, device="cuda")
+    _lib.check(L.udp_conv2d_wgrad(xd.data_ptr(), dyd.data_ptr(), n, h, w, cin_k, ho, wo, cout_k, ks, stride, cout, cin,
+                                  _lib.UDP_BF16, dw.data_ptr(), 0, ws.data_ptr(), ws.numel(), _stream()))
+    ref = wt.grad.numpy()
+    np.testing.assert_allclose(dw.cpu().numpy(), ref, rtol=0, atol=1e-4 * np.abs(ref).max())

@@ -188,6 +188,142 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16 weight gradient on the bf16 matrix pipe.  Same tiling / partial layout as wgrad_kernel; the
+// LDS images stay in the natural NHWC form [pixel][32 channels] (bf16, 80-byte rows) and both MFMA
+// operands -- A[m=co][k=pixel], B[k=pixel][n=ci], K-major per lane -- come out of them through
+// ds_read_b64_tr_b16 (gfx950 transposed LDS read: a 16-lane group reads 4 pixel rows x 16 channels and
+// each lane receives one channel's 4 pixels), so no transposed copy is ever written.
+// v_mfma_f32_32x32x16_bf16, fp32 accumulate.  The 4 waves take different 16-pixel k-steps of a unit
+// (all 9 taps each) and are summed through LDS at the end; units are register-prefetched one ahead.
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWbPitch = 80;      // bytes per staged pixel row (32 bf16 channels + 16 B)
+constexpr int kWbItems = 8;       // 16-byte staging items per thread (rows*4/256 <= 8: up to 512 staged rows)
+
+__device__ __forceinline__ bf16x8 tr_read8(const char* lds_lo, const char* lds_hi) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds_lo));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds_hi));
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int KS>
+__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradParams p) {
+  extern __shared__ char ldsb[];
+  constexpr int TAPS = KS * KS, PAD = KS / 2;
+  const int PX = p.TH * p.TW, PXP = (PX + 15) & ~15;
+  const int XR = p.XH * p.XW, ROWS = PXP + XR;
+  char* sDy = ldsb;                       // [PXP] rows
+  char* sX = ldsb + PXP * kWbPitch;       // [XH*XW] rows
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int ci0 = (blockIdx.x % p.tiles_ci) * 32, co0 = (blockIdx.x / p.tiles_ci) * 32;
+  const __bf16* gx = reinterpret_cast<const __bf16*>(p.x);
+  const __bf16* gdy = reinterpret_cast<const __bf16*>(p.dy);
+
+  // staging plan of this thread (the tile geometry is the same for every unit)
+  int it_row[kWbItems], it_a[kWbItems], it_b[kWbItems];      // row in LDS; (ty,tx) or (xy,xx)
+#pragma unroll
+  for (int k = 0; k < kWbItems; ++k) {
+    const int item = t + k * 256, r = item >> 2;
+    it_row[k] = r < ROWS ? r : -1;
+    if (r < PXP) {
+      it_a[k] = r / p.TW;
+      it_b[k] = r % p.TW;
+    } else {
+      it_a[k] = (r - PXP) / p.XW;
+      it_b[k] = (r - PXP) % p.XW;
+    }
+  }
+  const int seg = (t & 3) * 8;            // first of the 8 channels of this thread's 16-byte items
+
+  // operand addresses of this lane (one k-step per wave and unit when PXP <= 64; more via the loop)
+  const int g = lane >> 4, li = lane & 15, q4 = li >> 2, pp = li & 3;
+  const int colb = (16 * (g & 1) + 4 * pp) * 2;              // byte offset of the 4 channels this lane addresses
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int i = 0; i < TAPS; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  const int u0 = blockIdx.y * p.upw, u1 = min(u0 + p.upw, p.units);
+  const int upi = p.units_y * p.units_x;
+  u32x4 regs[kWbItems];
+
+  auto fetch = [&](int u) {
+    const int n = u / upi, ur = u % upi;
+    const int oy0 = (ur / p.units_x) * p.TH, ox0 = (ur % p.units_x) * p.TW;
+    const int iy0 = oy0 * p.stride - PAD, ix0 = ox0 * p.stride - PAD;
+#pragma unroll
+    for (int k = 0; k < kWbItems; ++k) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      const int r = it_row[k];
+      if (r >= 0) {
+        if (r < PXP) {
+          const int oy = oy0 + it_a[k], ox = ox0 + it_b[k];
+          if (r < PX && oy < p.Hout && ox < p.Wout && co0 + seg < p.CoutK)
+            v = *reinterpret_cast<const u32x4*>(gdy + (((long)n * p.Hout + oy) * p.Wout + ox) * p.CoutK + co0 + seg);
+        } else {
+          const int iy = iy0 + it_a[k], ix = ix0 + it_b[k];
+          if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win && ci0 + seg < p.CinK)
+            v = *reinterpret_cast<const u32x4*>(gx + (((long)n * p.Hin + iy) * p.Win + ix) * p.CinK + ci0 + seg);
+        }
+      }
+      regs[k] = v;
+    }
+  };
+
+  if (u0 < u1) fetch(u0);
+  for (int u = u0; u < u1; ++u) {
+    __syncthreads();                      // previous unit's operand reads are done
+#pragma unroll
+    for (int k = 0; k < kWbItems; ++k)
+      if (it_row[k] >= 0) *reinterpret_cast<u32x4*>(ldsb + it_row[k] * kWbPitch + seg * 2) = regs[k];
+    __syncthreads();
+    if (u + 1 < u1) fetch(u + 1);         // next unit's global loads fly under the MFMAs
+    for (int k0 = wave * 16; k0 < PXP; k0 += 64) {
+      const int r0 = k0 + 8 * (g >> 1) + q4;                 // pixel rows this lane addresses: r0 and r0 + 4
+      const bf16x8 a = tr_read8(sDy + r0 * kWbPitch + colb, sDy + (r0 + 4) * kWbPitch + colb);
+      const int qa = min(r0, PX - 1), qb = min(r0 + 4, PX - 1);   // padded pixels carry dy == 0
+      const char* xa = sX + (((qa / p.TW) * p.stride) * p.XW + (qa % p.TW) * p.stride) * kWbPitch + colb;
+      const char* xb = sX + (((qb / p.TW) * p.stride) * p.XW + (qb % p.TW) * p.stride) * kWbPitch + colb;
+#pragma unroll
+      for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+          const int off = (ky * p.XW + kx) * kWbPitch;
+          const bf16x8 b = tr_read8(xa + off, xb + off);
+          acc[ky * KS + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[ky * KS + kx], 0, 0, 0);
+        }
+    }
+  }
+  // sum the 4 waves through LDS, tap by tap; D[m = 8*(i/4) + 4*(lane/32) + i%4][n = lane%32]
+  float* red = reinterpret_cast<float*>(ldsb);               // [4][1024]
+  float* dst = p.part + (long)blockIdx.y * TAPS * p.cout * p.cin;
+#pragma unroll
+  for (int tp = 0; tp < TAPS; ++tp) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int m = 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3);
+      red[wave * 1024 + m * 32 + (lane & 31)] = acc[tp][i];
+    }
+    __syncthreads();
+    for (int e = t; e < 1024; e += 256) {
+      const float v = red[e] + red[1024 + e] + red[2048 + e] + red[3072 + e];
+      const int co = co0 + (e >> 5), ci = ci0 + (e & 31);
+      if (co < p.cout && ci < p.cin) dst[((long)tp * p.cout + co) * p.cin + ci] = v;
+    }
+  }
+}
+
 // dw[co][ci][tap] (+)= sum_s part[s][tap][co][ci].  Block = 16 element quads x 16 split lanes
 // (fixed summation order: deterministic).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int splits, int taps, int cout,
@@ -595,15 +731,20 @@ extern "C" int udp_conv2d_wgrad(const void* x, const void* dy, int n, int hin, i
   p.part = reinterpret_cast<float*>(workspace);
   p.N = n; p.Hin = hin; p.Win = win; p.CinK = cin_k; p.Hout = hout; p.Wout = wout; p.CoutK = cout_k; p.stride = stride;
   p.cout = cout; p.cin = cin;
-  const int maxpx = stride == 1 ? 64 : 32;
-  const int nseg = (wout + maxpx - 1) / maxpx;
+  const bool bf = dtype == UDP_BF16 && getenv("UDP_POSE_WGRAD_F32MFMA") == nullptr;
+  // fp32 kernel: <= 64 pixels per unit; bf16 kernel: up to 256 pixels / 512 staged rows per unit (fewer, larger
+  // global round trips: its MFMA time per unit is far below one HBM latency)
+  const int maxpx = bf ? 256 : (stride == 1 ? 64 : 32);
+  const int nseg = (wout + (bf ? 63 : maxpx - 1)) / (bf ? 64 : maxpx);
   p.TW = (wout + nseg - 1) / nseg;
   p.TH = 1;
-  for (int th = maxpx / p.TW; th > 1; --th)
-    if (hout % th == 0) {
+  for (int th = maxpx / p.TW; th > 1; --th) {
+    const int rows = ((th * p.TW + 15) & ~15) + ((th - 1) * stride + ks) * ((p.TW - 1) * stride + ks);
+    if (hout % th == 0 && (!bf || rows <= kWbItems * 64)) {
       p.TH = th;
       break;
     }
+  }
   p.units_x = (wout + p.TW - 1) / p.TW;
   p.units_y = (hout + p.TH - 1) / p.TH;
   p.units = n * p.units_x * p.units_y;
@@ -612,21 +753,32 @@ extern "C" int udp_conv2d_wgrad(const void* x, const void* dy, int n, int hin, i
   p.tiles_ci = (cin + 31) / 32;
   const int tiles = p.tiles_ci * ((cout + 31) / 32);
   const size_t per = (size_t)ks * ks * cout * cin * sizeof(float);
-  static const int target_wgs = getenv("UDP_POSE_WGRAD_WGS") ? atoi(getenv("UDP_POSE_WGRAD_WGS")) : 1024;
-  int splits = (target_wgs + tiles - 1) / tiles;           // aim at >= 1024 workgroups (4 per CU)
+  // fp32 kernel: 4 workgroups per CU; bf16 kernel (one resident workgroup per CU, 144 accumulator AGPRs): 1 per CU
+  static const int env_wgs = getenv("UDP_POSE_WGRAD_WGS") ? atoi(getenv("UDP_POSE_WGRAD_WGS")) : 0;
+  const int target_wgs = env_wgs > 0 ? env_wgs : (bf ? 256 : 1024);
+  int splits = (target_wgs + tiles - 1) / tiles;
   if (splits > p.units) splits = p.units;
   if ((size_t)splits * per > workspace_bytes) splits = (int)(workspace_bytes / per);
   if (splits < 1) return fail(UDP_ERR_ARG, "udp_conv2d_wgrad: workspace of %zu bytes is smaller than one partial (%zu)", workspace_bytes, per);
   p.upw = (p.units + splits - 1) / splits;
   splits = (p.units + p.upw - 1) / p.upw;
-  const int pxp = (p.TH * p.TW + 3) & ~3;
-  const unsigned lds = (unsigned)((pxp + p.XH * p.XW) * kWgPitch * sizeof(float));
+  const int pxp = bf ? (p.TH * p.TW + 15) & ~15 : (p.TH * p.TW + 3) & ~3;
+  unsigned lds = (unsigned)((pxp + p.XH * p.XW) * kWgPitch * sizeof(float));
+  if (bf) {
+    const int rows = pxp + p.XH * p.XW;
+    if (rows * 4 > kWbItems * 256) return fail(UDP_ERR_UNSUPPORTED, "udp_conv2d_wgrad: tile of %d rows exceeds the staging plan", rows);
+    if ((cin_k & 7) || (cout_k & 7)) return fail(UDP_ERR_ARG, "udp_conv2d_wgrad: bf16 channel pitches must be multiples of 8");
+    lds = (unsigned)(rows * kWbPitch);
+    if (lds < 4 * 1024 * sizeof(float)) lds = 4 * 1024 * sizeof(float);     // the cross-wave reduction buffer
+  }
   if (lds > 160 * 1024) return fail(UDP_ERR_UNSUPPORTED, "udp_conv2d_wgrad: tile needs %u bytes of LDS", lds);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const dim3 grid(tiles, splits);
   const void* fn;
   if (dtype == UDP_F32)
     fn = ks == 3 ? reinterpret_cast<const void*>(&wgrad_kernel<float, 3>) : reinterpret_cast<const void*>(&wgrad_kernel<float, 1>);
+  else if (bf)
+    fn = ks == 3 ? reinterpret_cast<const void*>(&wgrad_bf16_kernel<3>) : reinterpret_cast<const void*>(&wgrad_bf16_kernel<1>);
   else
     fn = ks == 3 ? reinterpret_cast<const void*>(&wgrad_kernel<__bf16, 3>) : reinterpret_cast<const void*>(&wgrad_kernel<__bf16, 1>);
   if (lds > 64 * 1024) UDP_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
