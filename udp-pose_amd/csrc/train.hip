@@ -401,6 +401,7 @@ __global__ __launch_bounds__(256) void bn_sums_kernel(const T* __restrict__ x, c
         mu = *reinterpret_cast<const f32x4*>(mean + cg * 4);
         is = *reinterpret_cast<const f32x4*>(invstd + cg * 4);
       }
+#pragma unroll 4
       for (long r = r0 + t / CT; r < r1; r += RG) {
         const f32x4 xv = ld4(x + r * C + cg * 4);
         if (MODE == 0) {
@@ -446,15 +447,15 @@ __global__ __launch_bounds__(256) void bn_sums_kernel(const T* __restrict__ x, c
   }
 }
 
-// Sum of the per-block partial rows for 16 channels per workgroup: 16 block lanes per channel, then a
+// Sum of the per-block partial rows for 4 channels per workgroup: 64 row lanes per channel, then a
 // fixed-order LDS reduction (deterministic).  Valid in threads with kl == 0.
 __device__ __forceinline__ void bn_collect(const double* ws, int nblocks, int C, int c, double& a, double& b) {
-  __shared__ double red[2][16][17];
-  const int cl = threadIdx.x & 15, kl = threadIdx.x >> 4;
+  __shared__ double red[2][64][5];
+  const int cl = threadIdx.x & 3, kl = threadIdx.x >> 2;
   a = 0.0;
   b = 0.0;
   if (c < C)
-    for (int k = kl; k < nblocks; k += 16) {
+    for (int k = kl; k < nblocks; k += 64) {
       a += ws[(long)k * 2 * C + c];
       b += ws[(long)k * 2 * C + C + c];
     }
@@ -462,7 +463,7 @@ __device__ __forceinline__ void bn_collect(const double* ws, int nblocks, int C,
   red[1][kl][cl] = b;
   __syncthreads();
   if (kl == 0) {
-    for (int k = 1; k < 16; ++k) {
+    for (int k = 1; k < 64; ++k) {
       a += red[0][k][cl];
       b += red[1][k][cl];
     }
@@ -472,10 +473,10 @@ __device__ __forceinline__ void bn_collect(const double* ws, int nblocks, int C,
 __global__ void bn_fwd_finalize_kernel(double* __restrict__ ws, int nblocks, long m, int C, float eps, float momentum,
                                        float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ smean,
                                        float* __restrict__ sinvstd) {
-  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+  const int c = blockIdx.x * 4 + (threadIdx.x & 3);
   double s0, s1;
   bn_collect(ws, nblocks, C, c, s0, s1);
-  if (c >= C || (threadIdx.x >> 4)) return;
+  if (c >= C || (threadIdx.x >> 2)) return;
   const double mu = s0 / (double)m;
   double var = s1 / (double)m - mu * mu;
   if (var < 0.0) var = 0.0;
@@ -507,10 +508,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
 
 __global__ void bn_bwd_finalize_kernel(double* __restrict__ ws, int nblocks, int C, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, float* __restrict__ sums) {
-  const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+  const int c = blockIdx.x * 4 + (threadIdx.x & 3);
   double s0, s1;
   bn_collect(ws, nblocks, C, c, s0, s1);
-  if (c >= C || (threadIdx.x >> 4)) return;
+  if (c >= C || (threadIdx.x >> 2)) return;
   dbeta[c] = (float)s0;
   dgamma[c] = (float)s1;
   sums[c] = (float)s0;
@@ -803,7 +804,7 @@ extern "C" int udp_bn_train_fwd(const void* x, int64_t m, int c, const float* ga
   UDP_DISPATCH_T(dtype,
                  (bn_sums_kernel<float, 0><<<nb, 256, 0, s>>>((const float*)x, nullptr, nullptr, nullptr, nullptr, m, c, ws)),
                  (bn_sums_kernel<__bf16, 0><<<nb, 256, 0, s>>>((const __bf16*)x, nullptr, nullptr, nullptr, nullptr, m, c, ws)));
-  bn_fwd_finalize_kernel<<<(c + 15) / 16, 256, 0, s>>>(ws, (int)nb, m, c, eps, momentum, running_mean, running_var, save_mean, save_invstd);
+  bn_fwd_finalize_kernel<<<(c + 3) / 4, 256, 0, s>>>(ws, (int)nb, m, c, eps, momentum, running_mean, running_var, save_mean, save_invstd);
   const long total4 = m * c / 4;
   UDP_DISPATCH_T(dtype,
                  (bn_apply_kernel<float><<<nblocks(total4, 256 * 2), 256, 0, s>>>((const float*)x, (const float*)res, save_mean, save_invstd, gamma, beta, total4, c, relu, (float*)y)),
@@ -824,7 +825,7 @@ extern "C" int udp_bn_train_bwd(const void* x, const void* dy, const void* y_rel
                  (bn_sums_kernel<float, 1><<<nb, 256, 0, s>>>((const float*)x, (const float*)dy, (const float*)y_relu, save_mean, save_invstd, m, c, ws)),
                  (bn_sums_kernel<__bf16, 1><<<nb, 256, 0, s>>>((const __bf16*)x, (const __bf16*)dy, (const __bf16*)y_relu, save_mean, save_invstd, m, c, ws)));
   float* sums = reinterpret_cast<float*>(ws + (size_t)kBnMaxBlocks * 2 * c);      // fp32 {dbeta, dgamma} after the partial rows
-  bn_bwd_finalize_kernel<<<(c + 15) / 16, 256, 0, s>>>(ws, (int)nb, c, dgamma, dbeta, sums);
+  bn_bwd_finalize_kernel<<<(c + 3) / 4, 256, 0, s>>>(ws, (int)nb, c, dgamma, dbeta, sums);
   const long total4 = m * c / 4;
   const float inv_m = 1.f / (float)m;
   UDP_DISPATCH_T(dtype,
