@@ -363,12 +363,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // Thread = 4 consecutive channels (16-byte loads) x one row lane; C % 4 == 0.
 constexpr int kBnMaxBlocks = 512;
 
+typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+
 template <typename T>
 __device__ __forceinline__ f32x4 ld4(const T* p) {
   if constexpr (std::is_same<T, float>::value) {
     return *reinterpret_cast<const f32x4*>(p);
   } else {
-    return f32x4{tof(p[0]), tof(p[1]), tof(p[2]), tof(p[3])};
+    const bf16x4v v = *reinterpret_cast<const bf16x4v*>(p);       // one 8-byte load
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
   }
 }
 template <typename T>
@@ -376,7 +379,7 @@ __device__ __forceinline__ void st4(T* p, f32x4 v) {
   if constexpr (std::is_same<T, float>::value) {
     *reinterpret_cast<f32x4*>(p) = v;
   } else {
-    p[0] = fromf<T>(v[0]); p[1] = fromf<T>(v[1]); p[2] = fromf<T>(v[2]); p[3] = fromf<T>(v[3]);
+    *reinterpret_cast<bf16x4v*>(p) = bf16x4v{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
   }
 }
 
