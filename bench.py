@@ -137,10 +137,34 @@ def roofline(net, hp, steps, dtype):
             "sum_kernel_ms_per_step": round(float(ms.sum()), 3), "classes": table}
 
 
+def usable_cpus():
+    """Host cores this process may really use: the affinity mask capped by the cgroup CPU quota (a GPU
+    box hands each job a share of the host; running torch's default one-thread-per-hardware-thread pool
+    against a smaller quota oversubscribes and slows the baseline down several times)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, q // int(f.read().split()[0])))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(sd, sample=8):
     """The CPU oracle on this box's host cores: forward + mirrored forward + flip fuse + DARK decode."""
     from oracle import decode as odec, flip as oflip, hrnet as ohrnet
-    cores = torch.get_num_threads()
+    cores = min(usable_cpus(), int(os.environ.get("UDP_POSE_CPU_THREADS", "64")))
+    torch.set_num_threads(cores)
     x = torch.from_numpy(synth.synth_crops(sample, 256, 192, seed=1))
     c, s = synth.synth_center_scale(sample, seed=1)
 
