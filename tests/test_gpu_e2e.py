@@ -291,3 +291,18 @@ def test_rsn18_matches_reference_heatmaps(golden_dir, och, tt):
     # Sanity only: this synthetic RSN amplifies rounding ~20x more than the synthetic HRNet (fp32 noise
     # 3e-4 vs 1.4e-5 against fp64), so bf16 storage lands near 50 % rms here; the fp32 mode is the parity mode.
     assert np.isfinite(rms) and rms < 0.8 * g["out"].std()
+
+
+def test_batches_past_the_launch_limit_are_split():
+    """A batch whose largest activation would exceed the 32-bit offsets of one launch is run in slices
+    (here the limit is lowered to 2 images): same result, flip-test row order kept (all plain rows, then
+    all mirrored rows)."""
+    extra = synth.scaled_extra(32, modules=(1, 1, 1), blocks=1)
+    sd = synth.synth_state_dict(extra, 17, "gaussian", seed=4)
+    net = MODELS["pose_hrnet"](_cfg(extra, 17, "gaussian"), is_train=False).load_state_dict(sd).to("cuda")
+    x = torch.from_numpy(synth.synth_crops(5, 64, 64, seed=8)).cuda()
+    whole_flip = net.raw_forward(x, flip_test=True).clone()
+    whole = net(x).clone()
+    net.max_images_per_launch = 2
+    torch.testing.assert_close(net.raw_forward(x, flip_test=True), whole_flip, rtol=0, atol=1e-6)
+    torch.testing.assert_close(net(x), whole, rtol=0, atol=1e-6)

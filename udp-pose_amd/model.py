@@ -34,6 +34,7 @@ class PoseHighResolutionNetHip:
         self.dtype = dtype
         self.device = None
         self.use_graph = True
+        self.max_images_per_launch = None     # None: only the 2 GiB-per-tensor limit of one launch applies
         self._sd = None
         self._compiled = {}      # (h, w) -> (handle, blob tensor, program)
         self._ws = None
@@ -143,6 +144,17 @@ class PoseHighResolutionNetHip:
         if n < 1:
             raise ValueError("empty batch (the reference's torch.stack of no crops raises too)")
         handle, _, prog = self._compiled.get((h, w)) or self._compile(h, w)
+        # one launch addresses a tensor with 32-bit byte offsets: split batches whose largest activation
+        # ([2N, H/2, W/2, 64]) would pass 2 GiB
+        cap = max(1, (2 ** 31 - 1) // (max(t.elems for t in prog._tensors) * (2 if self.dtype == "bf16" else 4)
+                                      * (2 if flip_test else 1)))
+        cap = min(cap, self.max_images_per_launch or cap)
+        if n > cap:
+            parts = [self.raw_forward(x[i:i + cap].contiguous(), flip_test).clone() for i in range(0, n, cap)]
+            if not flip_test:
+                return torch.cat(parts)
+            sizes = [min(cap, n - i) for i in range(0, n, cap)]
+            return torch.cat([p[:k] for p, k in zip(parts, sizes)] + [p[k:] for p, k in zip(parts, sizes)])
         xin, out = self.io_buffers(n, h, w, flip_test)
         if x.data_ptr() != xin.data_ptr():
             xin.copy_(x)
@@ -189,6 +201,7 @@ class RSN18Hip(PoseHighResolutionNetHip):
         self.dtype = dtype
         self.device = None
         self.use_graph = True
+        self.max_images_per_launch = None     # None: only the 2 GiB-per-tensor limit of one launch applies
         self._sd = None
         self._compiled = {}
         self._ws = None
