@@ -161,6 +161,36 @@ __device__ __forceinline__ void add_vec_buf(f32x4 (&v)[NB], __amdgpu_buffer_rsrc
     }
   }
 }
+// split form of add_vec_buf: issue the loads early, add later (persistent kernel: the residual of tile t
+// flies under tile t's MFMAs)
+template <typename T, int NB>
+struct ResRegs {
+  u32x4 r[std::is_same<T, float>::value ? NB : NB / 2];
+};
+template <typename T, int NB>
+__device__ __forceinline__ void load_res_buf(ResRegs<T, NB>& o, __amdgpu_buffer_rsrc_t r, unsigned voff) {
+  constexpr int N = std::is_same<T, float>::value ? NB : NB / 2;
+#pragma unroll
+  for (int h = 0; h < N; ++h) o.r[h] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + 16 * h, 0, 0);
+}
+template <typename T, int NB>
+__device__ __forceinline__ void add_res_regs(f32x4 (&v)[NB], const ResRegs<T, NB>& o) {
+  if constexpr (std::is_same<T, float>::value) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) v[nb] += __builtin_bit_cast(f32x4, o.r[nb]);
+  } else {
+#pragma unroll
+    for (int h = 0; h < NB / 2; ++h) {
+      const u32x4 x = o.r[h];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const unsigned wlo = x[q >> 1], whi = x[2 + (q >> 1)];
+        v[2 * h][q] += __builtin_bit_cast(float, (q & 1) ? (wlo & 0xFFFF0000u) : (wlo << 16));
+        v[2 * h + 1][q] += __builtin_bit_cast(float, (q & 1) ? (whi & 0xFFFF0000u) : (whi << 16));
+      }
+    }
+  }
+}
 template <typename T, int NB>
 __device__ __forceinline__ void store_vec_buf(__amdgpu_buffer_rsrc_t r, unsigned voff, const f32x4 (&v)[NB]) {
   if constexpr (std::is_same<T, float>::value) {
@@ -358,6 +388,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
 
   UDP_STAMP(1);
   stage(0, smem);
+  // The residual is added into the accumulators up front (acc = bias + res, then += conv): its loads fly
+  // behind chunk 0's DMA and land under the same wait, instead of a second exposed round trip in the
+  // epilogue.  Same sum, different fp32 order.
+  if constexpr (!NCHW) {
+    if (p.res) {
+#pragma unroll
+      for (int i = 0; i < MBW; ++i)
+        add_vec_buf<T, NB>(acc[i], r_res, opix[i] >= 0 ? (unsigned)opix[i] * respb + (p.res_coff + cbase) * ESZ : kOobOff);
+    }
+  }
   UDP_STAMP(2);
   for (int c = 0; c < nchunks; ++c) {
     // chunk c has landed (explicit wait: the compiler is not obliged to track LDS-DMA) and every
@@ -395,7 +435,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
         }
     } else {
       const unsigned ooff = opix[i] >= 0 ? (unsigned)opix[i] * outpb + (p.out_coff + cbase) * ESZ : kOobOff;
-      if (p.res) add_vec_buf<T, NB>(v, r_res, opix[i] >= 0 ? (unsigned)opix[i] * respb + (p.res_coff + cbase) * ESZ : kOobOff);
       if (p.nup) {   // wave-uniform, rare (exchange-unit outputs only)
         const int crd = ocrd[i];
         const int y = crd & 1023, xo = (crd >> 10) & 1023, n = crd >> 20;
@@ -558,6 +597,21 @@ __global__ __launch_bounds__(256) void conv_mfma_persist1(const ConvParams p) {
     if (t + (int)gridDim.x < ntiles) stage_in(t + gridDim.x, in_lds + ((it + 1) & 1) * in_bytes);
     const unsigned char* sb = in_lds + (it & 1) * in_bytes;
 
+    int n0, y0, x0;
+    tile_origin(t, n0, y0, x0);
+    const int o_org = ((n0 * p.Hout + y0) * p.Wout + x0) * p.Cout * ESZ;
+    // residual of this tile: loads issued here, consumed in the epilogue (they fly under the MFMAs)
+    ResRegs<T, NB> rres[MBW];
+    if (p.res) {
+#pragma unroll
+      for (int i = 0; i < MBW; ++i) {
+        const int crd = o_crd[i];
+        const int y = y0 + (crd & 1023), xo = x0 + ((crd >> 10) & 1023), n = n0 + ((crd >> 20) & 1023);
+        const bool ok = crd >= 0 && y < p.Hout && xo < p.Wout && n < p.N;
+        load_res_buf<T, NB>(rres[i], r_res, ok ? (unsigned)(o_org + o_rel[i]) : kOobOff);
+      }
+    }
+
     f32x4 acc[MBW][NB];
 #pragma unroll
     for (int i = 0; i < MBW; ++i)
@@ -566,9 +620,6 @@ __global__ __launch_bounds__(256) void conv_mfma_persist1(const ConvParams p) {
     mfma_chunk<T, KS, NB, MBW>(acc, sb, w_lds + li * ROWB, prow, IW, kg, wswz);
 
     // ---- epilogue of tile t
-    int n0, y0, x0;
-    tile_origin(t, n0, y0, x0);
-    const int o_org = ((n0 * p.Hout + y0) * p.Wout + x0) * p.Cout * ESZ;
 #pragma unroll
     for (int i = 0; i < MBW; ++i) {
       const int crd = o_crd[i];
@@ -578,7 +629,7 @@ __global__ __launch_bounds__(256) void conv_mfma_persist1(const ConvParams p) {
       f32x4 v[NB];
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) v[nb] = acc[i][nb];
-      if (p.res) add_vec_buf<T, NB>(v, r_res, voff);
+      if (p.res) add_res_regs<T, NB>(v, rres[i]);
       if (p.nup) {   // wave-uniform, rare
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
