@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UDP_POSE_ABI_VERSION 8
+#define UDP_POSE_ABI_VERSION 9
 
 enum udp_status {
   UDP_OK = 0,
@@ -69,6 +69,8 @@ enum udp_op_kind {
   UDP_OP_PSA_POOL = 6,  /* in = x [C];   out = fp32 {sum_p softmax(wq.x)_p x_p, mean_p x_p}  (2C floats) */
   UDP_OP_PSA_MLP = 7,   /* in = POOL out; out = fp32 {channel mask m[C], gbar[C/2]}            (3C/2 floats) */
   UDP_OP_PSA_SCALE = 8, /* in = x, res = MLP out; out = x * m[c] */
+  UDP_OP_BLOCK = 10,    /* fused BasicBlock, bf16, 32 channels: out = relu(conv3x3(relu(conv3x3(in)+b)) + b2 + in);
+                           w_off/b_off = first conv, w2_off/b2_off = second conv (pose_hrnet.py:43-59) */
   UDP_OP_PSA_SP = 9     /* in = theta [C/2] (1x1 conv of the scaled map), res = scaled map [C], up_buf[0] = MLP out;
                            out = res * sigmoid(sum_j gbar_j softmax_HW(theta_j)) */
 };
@@ -101,6 +103,7 @@ typedef struct udp_conv_op {
                               (HRNet branches); lane 0 runs on the caller's stream */
   int32_t n_wait;          /* cross-lane dependencies: this op starts after ops wait_op[0..n_wait) */
   int32_t wait_op[UDP_MAX_WAIT];
+  int64_t w2_off, b2_off;  /* UDP_OP_BLOCK: the second conv's weights / bias in the blob */
 } udp_conv_op;
 
 typedef struct udp_hrnet udp_hrnet; /* opaque */

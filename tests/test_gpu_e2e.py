@@ -306,3 +306,31 @@ def test_batches_past_the_launch_limit_are_split():
     net.max_images_per_launch = 2
     torch.testing.assert_close(net.raw_forward(x, flip_test=True), whole_flip, rtol=0, atol=1e-6)
     torch.testing.assert_close(net(x), whole, rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("h,w", [(256, 192), (128, 96), (64, 64), (32, 32)])
+def test_fused_basic_block_equals_the_two_conv_launches(h, w, monkeypatch):
+    """bf16: the fused BasicBlock kernel (32-channel branch: intermediate map and residual stay in LDS) against
+    the same network run as separate conv launches.  Both round the intermediate map to bf16; the residual
+    is added in a different fp32 order, so outputs agree to bf16 rounding of the activations."""
+    extra = synth.scaled_extra(32, modules=(1, 2, 1), blocks=2)
+    sd = synth.synth_state_dict(extra, 17, "gaussian", seed=12)
+    x = torch.from_numpy(synth.synth_crops(3, h, w, seed=13))
+    ohrnet.hrnet_forward(sd, extra, x, calibrate=True)
+    outs = {}
+    for fused in (True, False):
+        if fused:
+            monkeypatch.delenv("UDP_POSE_NO_BLOCK_FUSION", raising=False)
+        else:
+            monkeypatch.setenv("UDP_POSE_NO_BLOCK_FUSION", "1")
+        net = MODELS["pose_hrnet"](_cfg(extra, 17, "gaussian"), is_train=False, dtype="bf16").load_state_dict(sd).to("cuda")
+        kinds = [d[1] for d in net.program(h, w).describe()]
+        assert (kinds.count(10) > 0) == fused
+        outs[fused] = net.raw_forward(x.cuda(), flip_test=True).clone().float().cpu().numpy()
+    ref = ohrnet.hrnet_forward(sd, extra, torch.cat([x, torch.flip(x, dims=[3])])).numpy()
+    d = outs[True] - outs[False]
+    assert np.sqrt((d ** 2).mean()) < 1.5e-2 * ref.std(), (np.sqrt((d ** 2).mean()), ref.std())
+    # and the fused path is as close to the fp32 oracle as the unfused one
+    e_f = np.sqrt(((outs[True] - ref) ** 2).mean())
+    e_u = np.sqrt(((outs[False] - ref) ** 2).mean())
+    assert e_f < 1.15 * e_u + 1e-4, (e_f, e_u)

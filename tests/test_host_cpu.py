@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libudp_pose_hip.so does not export %s" % name
     assert declared == set(_lib.EXPORTS)
-    assert lib.udp_abi_version() == _lib.ABI_VERSION == 8
+    assert lib.udp_abi_version() == _lib.ABI_VERSION == 9
 
 
 def test_argument_validation_without_gpu():
@@ -61,7 +61,9 @@ def test_program_census_matches_survey(dtype):
     prog = hrnet_plan.HRNetProgram(sd, synth.W32_EXTRA, 256, 192, dtype)
     kinds = [d[1] for d in prog.describe()]
     assert kinds.count(_lib.UDP_OP_STEM) == 1
-    assert kinds.count(_lib.UDP_OP_STEM) + kinds.count(_lib.UDP_OP_CONV) == 294     # 294 convs
+    n_block = kinds.count(_lib.UDP_OP_BLOCK)       # bf16: the 32 BasicBlocks of the 32-channel branch are one launch each
+    assert n_block == (32 if dtype == "bf16" else 0)
+    assert kinds.count(_lib.UDP_OP_STEM) + kinds.count(_lib.UDP_OP_CONV) + 2 * n_block == 294     # 294 convs
     assert prog.macs_per_image() == 7670857728                                        # 7.671 GMAC
     ops = prog.ops_array()
     assert ops[len(ops) - 1].out_buf == _lib.UDP_BUF_OUTPUT and ops[len(ops) - 1].cout == 17
@@ -129,8 +131,8 @@ def test_psa_program_emission():
     """pose_hrnet_psa: five ops per BasicBlock (pool, mlp, scale, theta conv, sp) between conv1 and conv2."""
     extra = synth.scaled_extra(32, modules=(1, 2, 1), blocks=2)
     sd = synth.synth_state_dict(extra, 17, "gaussian", seed=6, psa=True)
-    prog = hrnet_plan.HRNetProgram(sd, extra, 128, 96, "bf16")
-    plain = hrnet_plan.HRNetProgram({k: v for k, v in sd.items() if ".deattn." not in k}, extra, 128, 96, "bf16")
+    prog = hrnet_plan.HRNetProgram(sd, extra, 128, 96, "f32")
+    plain = hrnet_plan.HRNetProgram({k: v for k, v in sd.items() if ".deattn." not in k}, extra, 128, 96, "f32")
     n_blocks = sum(1 for k in sd if k.endswith(".deattn.conv_q_right.weight"))
     assert n_blocks == 2 * (2 * 1 + 3 * 2 + 4 * 1)
     assert len(prog.describe()) == len(plain.describe()) + 5 * n_blocks
@@ -144,4 +146,4 @@ def test_psa_program_emission():
             assert arr[i - 1].kind == _lib.UDP_OP_CONV and arr[i - 1].cout == arr[i].cin      # theta
     with pytest.raises(ValueError):
         sd48 = synth.synth_state_dict(synth.scaled_extra(48, modules=(1, 1, 1), blocks=1), 17, "gaussian", seed=6, psa=True)
-        hrnet_plan.HRNetProgram(sd48, synth.scaled_extra(48, modules=(1, 1, 1), blocks=1), 128, 96, "bf16")
+        hrnet_plan.HRNetProgram(sd48, synth.scaled_extra(48, modules=(1, 1, 1), blocks=1), 128, 96, "f32")

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Experiment: K independent half/quarter batches on K streams (each its own graph replay) vs one batch on
+one stream.  Kernels of different streams may co-execute and fill each other's ramp-up / drain gaps."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+
+def run(total, k, steps=30, warmup=5):
+    dev = torch.device("cuda", 0)
+    sd, _ = bench.build_net("bf16")
+    hps, streams = [], []
+    for i in range(k):
+        _, net = bench.build_net("bf16")
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            hps.append(bench.HotPath(net, total // k, dev, seed=1 + i))
+        streams.append(s)
+    def step():
+        for hp, s in zip(hps, streams):
+            with torch.cuda.stream(s):
+                hp.step()
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / steps
+    print("batch %d as %d stream(s): %.3f ms/step, %.0f img/s" % (total, k, dt * 1e3, total / dt), flush=True)
+
+for total, k in ((64, 1), (64, 2), (64, 4), (128, 2)):
+    run(total, k)

@@ -39,6 +39,8 @@ struct ConvParams {
   void* out;
   const void* wgt;
   const float* bias;
+  const void* wgt2;      // fused BasicBlock: second conv's weights / bias
+  const float* bias2;
   const void* res;
   const void* up[3];
   int up_shift[3];

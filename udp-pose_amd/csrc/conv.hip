@@ -654,6 +654,198 @@ __global__ __launch_bounds__(256) void conv_mfma_persist1(const ConvParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused BasicBlock for the 32-channel high-resolution branch (bf16):
+//     out = relu( conv2( relu(conv1(x) + b1) ) + b2 + x )           pose_hrnet.py:43-59 with BN folded
+// The two 3x3 convs of this branch are the HBM-bound launches of the network (three 25 MB tensors
+// read + written per conv at batch 128 vs 7.8 GFLOP): fusing them keeps the intermediate map and the
+// residual (= the block input, already staged) in LDS -- 2 tensors of HBM traffic per block instead of 5.
+// Persistent workgroups (one per CU) walk tiles of R = 8 output rows x the full width: the input halo
+// tile (R+4 rows) is LDS-DMA'd one tile ahead; conv1 is evaluated on R+2 rows (25 % halo recompute)
+// and written (bias, ReLU, zero outside the image = conv2's zero padding) as bf16 into an LDS image with
+// the same swizzled row layout the DMA produces, so conv2 runs the same mfma_chunk on it.
+// Both weight blocks (2 x 18 KB) stay resident.
+// ---------------------------------------------------------------------------------------------
+constexpr int kBlkR = 8;
+constexpr int kBlkMaxG = 10;      // 16-row staging groups per wave: input tile <= 640 rows
+
+template <int MBW1, int MBW2, int NW>
+__global__ __launch_bounds__(NW * 64) void basic_block_c32_kernel(const ConvParams p) {
+  using T = __bf16;
+  constexpr int ESZ = 2, NB = 2, BN = 32, TAPS = 9, C = 32;
+  constexpr int WBYTES = TAPS * BN * ROWB;               // 18432
+  constexpr int WGROUPS = TAPS * BN / 16;
+  constexpr int NSTORE = MBW2 * (NB / 2);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15;
+  const int kg = lane >> 4;
+
+  const int H = p.Hin, W = p.Win;
+  const int IW = p.IW, IH = p.IH;                        // W + 2, R + 4
+  const int MH = kBlkR + 2;
+  const int npix_in = IH * IW, in_groups = (npix_in + 15) >> 4, in_bytes = in_groups * 16 * ROWB;
+  const int npix_mid = MH * IW, mid_bytes = ((npix_mid + 15) >> 4) * 16 * ROWB;
+  const int M1 = MH * W, M2 = kBlkR * W;
+  const unsigned cinb = C * ESZ;
+  unsigned char* const w1_lds = smem;
+  unsigned char* const w2_lds = smem + WBYTES;
+  unsigned char* const mid_lds = smem + 2 * WBYTES;
+  unsigned char* const in_lds = mid_lds + mid_bytes;     // two buffers
+
+  const unsigned npix = (unsigned)p.N * H * W;
+  const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, npix * cinb, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, TAPS * BN * cinb, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt2), 0, TAPS * BN * cinb, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, npix * cinb, 0x00020000);
+
+  // ---- tile-invariant per-lane state: staging
+  const int srow = lane >> 2, spart = lane & 3;
+  constexpr int SG = (kBlkMaxG * 4 + NW - 1) / NW;   // staging groups per wave
+  int s_rel[SG], s_crd[SG];                  // byte offset rel. to the tile origin; iy | ix << 10
+#pragma unroll
+  for (int i = 0; i < SG; ++i) {
+    s_rel[i] = 0;
+    s_crd[i] = -1;
+    if ((wave + NW * i) * 16 < npix_in) {
+      const int row = (wave + NW * i) * 16 + srow;
+      const int iy = fdiv20(row, p.mIW);
+      const int ix = row - (int)__umul24(iy, IW);
+      s_rel[i] = (int)((__umul24(iy, W) + ix) * cinb) + ((spart ^ swz(row)) << 4);
+      s_crd[i] = row < npix_in ? (iy | (ix << 10)) : -1;
+    }
+  }
+  // conv1: the lane's MBW1 mid pixels; conv2: its MBW2 output pixels
+  int prow1[MBW1], mrow1[MBW1];      // sIn row of the (0,0) tap; sMid row to write | mid row index << 16, -1 = none
+#pragma unroll
+  for (int i = 0; i < MBW1; ++i) {
+    const int m0 = (wave + NW * i) * 16 + li;
+    const int m = m0 < M1 ? m0 : M1 - 1;
+    const int mr = fdiv20(m, p.mTW);
+    const int mx = m - (int)__umul24(mr, W);
+    prow1[i] = (int)__umul24(mr, IW) + mx;
+    mrow1[i] = m0 < M1 ? (((int)__umul24(mr, IW) + mx + 1) | (mr << 16)) : -1;
+  }
+  int prow2[MBW2], o_rel[MBW2], o_r[MBW2];  // sMid row of the (0,0) tap; output byte offset rel. to the tile; row r or -1
+#pragma unroll
+  for (int i = 0; i < MBW2; ++i) {
+    const int m0 = (wave + NW * i) * 16 + li;
+    const int m = m0 < M2 ? m0 : M2 - 1;
+    const int r = fdiv20(m, p.mTW);
+    const int x = m - (int)__umul24(r, W);
+    prow2[i] = (int)__umul24(r, IW) + x;
+    o_rel[i] = (int)((__umul24(r, W) + x) * cinb) + 16 * kg;
+    o_r[i] = m0 < M2 ? r : -1;
+  }
+  const int wswz = swz(li);
+  const int cbase = 4 * NB * kg;     // the lane's 8 consecutive output channels
+  f32x4 bias1[NB], bias2[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    bias1[nb] = *reinterpret_cast<const f32x4*>(p.bias + cbase + 4 * nb);
+    bias2[nb] = *reinterpret_cast<const f32x4*>(p.bias2 + cbase + 4 * nb);
+  }
+
+  auto stage_in = [&](int t, unsigned char* sb) {
+    const int n = udiv16(t, p.mTY);
+    const int y0 = (t - n * p.tiles_y) * kBlkR;
+    const int gy0 = y0 - 2;
+    const int org = ((n * H + gy0) * W - 1) * (int)cinb;
+#pragma unroll
+    for (int i = 0; i < SG; ++i) {
+      const int gidx = wave + NW * i;
+      if (gidx < in_groups) {
+        const int crd = s_crd[i];
+        const int gy = gy0 + (crd & 1023), gx = ((crd >> 10) & 1023) - 1;
+        const bool ok = crd >= 0 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        blds16(r_in, ok ? (unsigned)(org + s_rel[i]) : kOobOff, sb + gidx * (16 * ROWB));
+      }
+    }
+  };
+
+  const int ntiles = p.ntiles;
+  int t = blockIdx.x;
+  if (t >= ntiles) return;
+  // zero the intermediate image once: its halo columns are never written again (conv2's zero padding)
+  for (int i = tid * 16; i < mid_bytes; i += NW * 64 * 16) *reinterpret_cast<u32x4*>(mid_lds + i) = u32x4{0u, 0u, 0u, 0u};
+  // both weight blocks once: LDS row (tap, nb*16 + r) holds cout 4*NB*(r>>2) + 4*nb + (r&3)
+  for (int gidx = wave; gidx < WGROUPS; gidx += NW) {
+    const int wr = gidx * 16 + srow;
+    const int tap = wr / BN;
+    const int rho = wr & (BN - 1);
+    const int co = (4 * NB) * ((rho & 15) >> 2) + 4 * (rho >> 4) + (rho & 3);
+    const unsigned e = (unsigned)(tap * BN + co) * cinb + ((spart ^ swz(wr)) << 4);
+    blds16(r_w1, e, w1_lds + gidx * (16 * ROWB));
+    blds16(r_w2, e, w2_lds + gidx * (16 * ROWB));
+  }
+  stage_in(t, in_lds);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  for (int it = 0; t < ntiles; t += gridDim.x, ++it) {
+    // this tile's input has landed in every wave's view after the barrier; nobody reads the other input
+    // buffer or the intermediate image of the previous tile any more
+    __builtin_amdgcn_s_barrier();
+    if (t + (int)gridDim.x < ntiles) stage_in(t + gridDim.x, in_lds + ((it + 1) & 1) * in_bytes);
+    const unsigned char* sb = in_lds + (it & 1) * in_bytes;
+    const int n = udiv16(t, p.mTY);
+    const int y0 = (t - n * p.tiles_y) * kBlkR;
+
+    {   // ---- conv1 on the R+2 intermediate rows -> LDS (bias, ReLU, zero outside the image)
+      f32x4 acc[MBW1][NB];
+#pragma unroll
+      for (int i = 0; i < MBW1; ++i)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[i][nb] = bias1[nb];
+      mfma_chunk<T, 3, NB, MBW1>(acc, sb, w1_lds + li * ROWB, prow1, IW, kg, wswz);
+#pragma unroll
+      for (int i = 0; i < MBW1; ++i) {
+        const int mr = mrow1[i] >> 16, row = mrow1[i] & 0xFFFF;
+        if (mrow1[i] >= 0) {
+          const bool inside = (unsigned)(y0 - 1 + mr) < (unsigned)H;
+          bf16x8 o;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float a = acc[i][0][q], b = acc[i][1][q];
+            o[q] = (__bf16)(inside && a > 0.f ? a : 0.f);
+            o[4 + q] = (__bf16)(inside && b > 0.f ? b : 0.f);
+          }
+          *reinterpret_cast<bf16x8*>(mid_lds + row * ROWB + ((kg ^ swz(row)) << 4)) = o;
+        }
+      }
+    }
+    __syncthreads();
+    {   // ---- conv2 from the LDS image + residual from the staged input -> global
+      f32x4 acc[MBW2][NB];
+#pragma unroll
+      for (int i = 0; i < MBW2; ++i)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[i][nb] = bias2[nb];
+      mfma_chunk<T, 3, NB, MBW2>(acc, mid_lds, w2_lds + li * ROWB, prow2, IW, kg, wswz);
+      const int o_org = ((n * H + y0) * W) * (int)cinb;
+#pragma unroll
+      for (int i = 0; i < MBW2; ++i) {
+        const int r = o_r[i];
+        const bool ok = r >= 0 && y0 + r < H;
+        const int rrow = prow2[i] + 2 * IW + 1;                 // the block input at the output pixel
+        const bf16x8 x = *reinterpret_cast<const bf16x8*>(sb + rrow * ROWB + ((kg ^ swz(rrow)) << 4));
+        bf16x8 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float a = acc[i][0][q] + (float)x[q], b = acc[i][1][q] + (float)x[4 + q];
+          o[q] = (__bf16)(a > 0.f ? a : 0.f);
+          o[4 + q] = (__bf16)(b > 0.f ? b : 0.f);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), r_out, ok ? (unsigned)(o_org + o_rel[i]) : kOobOff, 0, 0);
+      }
+    }
+    // the next tile's DMA was issued before this tile's NSTORE stores
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
+  }
+}
+
 // Stem conv1: 3x3 stride-2 conv on the NCHW fp32 network input (Cin = 3), direct
 // VALU form (27 taps), + folded BN + ReLU, NHWC output.  pose_hrnet.py:290-292,
 // :437-439.  Images n >= flip_from read image n - flip_from mirrored along W
@@ -1018,6 +1210,60 @@ static int describe_persist(const ConvParams& p, int ks, int stride, int nb, int
   UDP_CASE(3, 1, 2) UDP_CASE(3, 1, 4) UDP_CASE(3, 2, 2) UDP_CASE(3, 2, 4) UDP_CASE(1, 1, 2) UDP_CASE(1, 1, 4)
 #undef UDP_CASE
   return 1;
+}
+
+// Fused BasicBlock (bf16, 32 channels): returns 1 when the shape does not qualify.
+template <int MBW1, int MBW2, int NW>
+static int describe_block_one(const ConvParams& p, size_t lds, int grid_x, Launch* out) {
+  static bool attr_set = false;
+  const void* kern = reinterpret_cast<const void*>(&basic_block_c32_kernel<MBW1, MBW2, NW>);
+  if (!attr_set) {
+    UDP_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  out->fn = kern;
+  out->grid = dim3(grid_x);
+  out->block = dim3(NW * 64);
+  out->lds = (unsigned)lds;
+  out->p = p;
+  return UDP_OK;
+}
+
+int describe_block(ConvParams p, int dtype, Launch* out) {
+  if (dtype != UDP_BF16 || p.Cin != 32 || p.Cout != 32) return fail(UDP_ERR_UNSUPPORTED, "fused BasicBlock: bf16 with 32 channels only");
+  if (p.Hin % kBlkR || p.Hin != p.Hout || p.Win != p.Wout) return fail(UDP_ERR_UNSUPPORTED, "fused BasicBlock: height must be a multiple of %d", kBlkR);
+  p.R = kBlkR;
+  p.IH = kBlkR + 4;
+  p.IW = p.Win + 2;
+  p.TW = p.Win;
+  p.G = 1;
+  const int rows_in = p.IH * p.IW, rows_mid = (kBlkR + 2) * p.IW;
+  if (rows_in > kBlkMaxG * 64) return fail(UDP_ERR_UNSUPPORTED, "fused BasicBlock: map too wide (%d)", p.Win);
+  const int m1 = (kBlkR + 2) * p.Win, m2 = kBlkR * p.Win;
+  // 8 waves (two per SIMD) for the wide maps: one workgroup per CU has to hide its own LDS / MFMA latencies
+  int nw = m2 > 128 && getenv("UDP_POSE_BLOCK_4W") == nullptr ? 8 : 4;
+  if (m2 > 256 && getenv("UDP_POSE_BLOCK_16W") != nullptr) nw = 16;
+  const int mbw1 = ceil_div(m1, nw * 16), mbw2 = ceil_div(m2, nw * 16);
+  p.tiles_x = 1;
+  p.tiles_y = p.Hin / kBlkR;
+  p.ntiles = p.N * p.tiles_y;
+  if (p.ntiles >= 65536) return fail(UDP_ERR_UNSUPPORTED, "fused BasicBlock: too many tiles");
+  auto magic20 = [](int d) { return (unsigned)(((1u << 20) + d - 1) / d); };
+  auto magic32 = [](int d) { return d == 1 ? 0u : (unsigned)((0x100000000ULL + (unsigned)d - 1) / (unsigned)d); };
+  p.mIW = magic20(p.IW);
+  p.mTW = magic20(p.Win);
+  p.mTY = magic32(p.tiles_y);
+  const size_t lds = 2 * 9 * 32 * ROWB + (size_t)((rows_mid + 15) / 16) * 16 * ROWB + 2 * (size_t)((rows_in + 15) / 16) * 16 * ROWB;
+  if (lds > 160 * 1024) return fail(UDP_ERR_UNSUPPORTED, "fused BasicBlock: %zu bytes of LDS", lds);
+  const int grid_x = p.ntiles < 256 ? p.ntiles : ceil_div(p.ntiles, ceil_div(p.ntiles, 256));
+  if (nw == 16 && mbw1 == 2 && mbw2 == 2) return describe_block_one<2, 2, 16>(p, lds, grid_x, out);
+  if (nw == 8 && mbw1 == 4 && mbw2 == 3) return describe_block_one<4, 3, 8>(p, lds, grid_x, out);   // 48 columns (256x192 input)
+  if (nw == 8 && mbw1 == 2 && mbw2 == 2) return describe_block_one<2, 2, 8>(p, lds, grid_x, out);   // 24 columns
+  if (nw == 4 && mbw1 == 8 && mbw2 == 6) return describe_block_one<8, 6, 4>(p, lds, grid_x, out);
+  if (nw == 4 && mbw1 == 4 && mbw2 == 3) return describe_block_one<4, 3, 4>(p, lds, grid_x, out);
+  if (nw == 4 && mbw1 == 3 && mbw2 == 2) return describe_block_one<3, 2, 4>(p, lds, grid_x, out);   // 16 columns (tests)
+  if (nw == 4 && mbw1 == 2 && mbw2 == 1) return describe_block_one<2, 1, 4>(p, lds, grid_x, out);
+  return fail(UDP_ERR_UNSUPPORTED, "fused BasicBlock: no kernel for %d columns", p.Win);
 }
 
 // Fills `out` with the kernel, grid and arguments of one fused conv (tile choice included).

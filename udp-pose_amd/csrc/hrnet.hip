@@ -15,6 +15,7 @@ int describe_stem7(const ConvParams& p, int dtype, Launch* out);
 int describe_maxpool(const ConvParams& p, int dtype, Launch* out);
 int describe_bilinear(const ConvParams& p, int dtype, Launch* out);
 int describe_psa(const ConvParams& p, int dtype, int kind, Launch* out);
+int describe_block(ConvParams p, int dtype, Launch* out);
 int run_launch(const Launch& l, hipStream_t s);
 }  // namespace udp
 
@@ -54,10 +55,23 @@ static int validate_op(const udp_hrnet* h, const udp_conv_op& o, int idx) {
   const int nb = (int)h->buf_elems.size();
   auto buf_ok = [&](int b, int64_t need) { return b >= 0 && b < nb && h->buf_elems[b] >= need; };
   const int64_t out_need = (int64_t)o.hout * o.wout * (o.out_pitch ? o.out_pitch : o.cout);
-  if (o.kind < UDP_OP_STEM || o.kind > UDP_OP_PSA_SP) return fail(UDP_ERR_ARG, "op %d: bad kind %d", idx, o.kind);
+  if (o.kind < UDP_OP_STEM || o.kind > UDP_OP_BLOCK) return fail(UDP_ERR_ARG, "op %d: bad kind %d", idx, o.kind);
   if (o.lane < 0 || o.lane >= UDP_MAX_LANES || o.n_wait < 0 || o.n_wait > UDP_MAX_WAIT) return fail(UDP_ERR_ARG, "op %d: lane/n_wait", idx);
   for (int k = 0; k < o.n_wait; ++k)
     if (o.wait_op[k] < 0 || o.wait_op[k] >= idx) return fail(UDP_ERR_ARG, "op %d: wait_op %d must name an earlier op", idx, o.wait_op[k]);
+  if (o.kind == UDP_OP_BLOCK) {
+    const int64_t hw = (int64_t)o.hin * o.win;
+    if (h->dtype != UDP_BF16 || o.cin != 32 || o.cout != 32 || o.hin != o.hout || o.win != o.wout || o.hin % 8)
+      return fail(UDP_ERR_ARG, "op %d: fused BasicBlock needs bf16, 32 channels, height %% 8 == 0", idx);
+    if (!buf_ok(o.in_buf, hw * 32) || !buf_ok(o.out_buf, hw * 32) || o.in_buf == o.out_buf)
+      return fail(UDP_ERR_ARG, "op %d: fused BasicBlock buffers", idx);
+    const size_t wbytes = (size_t)9 * 32 * 32 * 2;
+    const int64_t offs[4] = {o.w_off, o.w2_off, o.b_off, o.b2_off};
+    for (int k = 0; k < 4; ++k)
+      if (offs[k] < 0 || (size_t)offs[k] + (k < 2 ? wbytes : 32 * 4) > h->weights_bytes || (offs[k] & 15))
+        return fail(UDP_ERR_ARG, "op %d: fused BasicBlock weight/bias range outside the blob or misaligned", idx);
+    return UDP_OK;
+  }
   if (o.kind >= UDP_OP_PSA_POOL) {
     // polarized self-attention ops: per-image side buffers hold fp32 rows, counted in `dtype` elements
     const int64_t f = 4 / (int64_t)esize(h->dtype);
@@ -175,6 +189,7 @@ extern "C" int udp_hrnet_create(const udp_conv_op* ops, int n_ops, const int64_t
     has_out |= ops[i].out_buf == UDP_BUF_OUTPUT;
     if (ops[i].kind == UDP_OP_STEM || ops[i].kind == UDP_OP_STEM7 || ops[i].kind == UDP_OP_CONV)
       h->flops += 2.0 * ops[i].ks * ops[i].ks * ops[i].cin * ops[i].cout * ops[i].hout * ops[i].wout;
+    if (ops[i].kind == UDP_OP_BLOCK) h->flops += 2 * 2.0 * 9 * 32 * 32 * ops[i].hout * ops[i].wout;
     h->ops.push_back(ops[i]);
   }
   if (!has_out || (h->ops[0].kind != UDP_OP_STEM && h->ops[0].kind != UDP_OP_STEM7) || h->ops[0].lane != 0 || h->ops.back().lane != 0 ||
@@ -251,7 +266,12 @@ static int describe_all(const udp_hrnet* h, const float* in, int n, int flip, ch
       p.wgt = h->weights + o.w_off;
       p.bias = reinterpret_cast<const float*>(h->weights + o.b_off);
     }
-    if (o.kind >= UDP_OP_PSA_POOL) {
+    if (o.kind == UDP_OP_BLOCK) {
+      p.wgt = h->weights + o.w_off;
+      p.bias = reinterpret_cast<const float*>(h->weights + o.b_off);
+      p.wgt2 = h->weights + o.w2_off;
+      p.bias2 = reinterpret_cast<const float*>(h->weights + o.b2_off);
+    } else if (o.kind >= UDP_OP_PSA_POOL) {
       p.wgt = h->weights + o.w_off;
       if (o.kind == UDP_OP_PSA_SCALE) p.res_pitch = o.cin + o.cin / 2;   // fp32 rows {m[C], gbar[C/2]}
     }
@@ -261,6 +281,7 @@ static int describe_all(const udp_hrnet* h, const float* in, int n, int flip, ch
       case UDP_OP_PSA_MLP:
       case UDP_OP_PSA_SCALE:
       case UDP_OP_PSA_SP: rc = describe_psa(p, h->dtype, o.kind, &ls[i]); break;
+      case UDP_OP_BLOCK: rc = describe_block(p, h->dtype, &ls[i]); break;
       case UDP_OP_STEM: rc = describe_stem(p, h->dtype, &ls[i]); break;
       case UDP_OP_STEM7: rc = describe_stem7(p, h->dtype, &ls[i]); break;
       case UDP_OP_FUSE: rc = describe_fuse(p, h->dtype, &ls[i]); break;

@@ -17,6 +17,8 @@ emits one ``udp_conv_op`` (include/udp_pose_hip.h) per fused launch:
   last stage-4 module, the epilogue of its 1x1 C->4C conv, :213-221).
 * Activation buffers are assigned by a linear scan over tensor lifetimes.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -53,6 +55,7 @@ class HRNetProgram:
         self.extra = extra
         self.dtype = dtype
         self.in_h, self.in_w = in_h, in_w
+        self.fuse_blocks = os.environ.get("UDP_POSE_NO_BLOCK_FUSION") is None
         self._tensors = []
         self._ops = []          # dicts with _T references
         self._blob = []         # list of (offset, np.ndarray uint8)
@@ -113,6 +116,23 @@ class HRNetProgram:
         self._ops.append(dict(kind=_lib.UDP_OP_CONV, ks=ks, stride=stride, relu=int(relu), cin=cin, cout=cout,
                               cout_pad=cout_pad, hin=x.h, win=x.w, hout=ho, wout=wo, inp=x, out=out, res=res,
                               ups=list(ups), w_off=w_off, b_off=b_off, name=conv))
+        return out
+
+    def _can_fuse_block(self, x, q):
+        """The fused BasicBlock kernel (csrc/conv.hip basic_block_c32_kernel): bf16, 32 channels, rows in
+        tiles of 8, the staged (8+4) x (W+2) input tile within 640 LDS rows, no attention inside."""
+        return (self.dtype == "bf16" and self.fuse_blocks and x.c == 32 and x.h % 8 == 0 and 12 * (x.w + 2) <= 640
+                and x.w in (48, 24, 16, 8) and (q + ".deattn.conv_q_right.weight") not in self.sd
+                and tuple(self.sd[q + ".conv1.weight"].shape) == (32, 32, 3, 3)
+                and tuple(self.sd[q + ".conv2.weight"].shape) == (32, 32, 3, 3))
+
+    def _block(self, x, q):
+        w1, b1, _, _, _, _ = self._pack_conv(q + ".conv1", q + ".bn1")
+        w2, b2, _, _, _, _ = self._pack_conv(q + ".conv2", q + ".bn2")
+        out = self._new(32, x.h, x.w)
+        self._ops.append(dict(kind=_lib.UDP_OP_BLOCK, ks=3, stride=1, relu=1, cin=32, cout=32, cout_pad=32, hin=x.h,
+                              win=x.w, hout=x.h, wout=x.w, inp=x, out=out, res=None, ups=[], w_off=w1, b_off=b1,
+                              w2_off=w2, b2_off=b2, name=q + ".block"))
         return out
 
     def _psa(self, x, p):
@@ -204,6 +224,9 @@ class HRNetProgram:
         for b in range(nb):
             for k in range(num_blocks[b]):
                 q = "%s.branches.%d.%d" % (p, b, k)
+                if self._can_fuse_block(xs[b], q):
+                    xs[b] = self._block(xs[b], q)
+                    continue
                 t = self._conv(xs[b], q + ".conv1", q + ".bn1")
                 if (q + ".deattn.conv_q_right.weight") in self.sd:       # pose_hrnet_psa.py:37,49
                     t = self._psa(t, q + ".deattn")
@@ -314,7 +337,7 @@ class HRNetProgram:
             o.in_buf = _lib.UDP_BUF_NONE if op["inp"] is None else self._phys[op["inp"].id]
             o.out_buf = _lib.UDP_BUF_OUTPUT if op["out"] is None else self._phys[op["out"].id]
             o.res_buf = _lib.UDP_BUF_NONE if op["res"] is None else self._phys[op["res"].id]
-            for f in ("in_coff", "in_pitch", "out_coff", "out_pitch", "res_coff", "res_pitch"):
+            for f in ("in_coff", "in_pitch", "out_coff", "out_pitch", "res_coff", "res_pitch", "w2_off", "b2_off"):
                 setattr(o, f, op.get(f, 0))
             o.lane = op["lane"]
             o.n_wait = len(op["wait"])
@@ -337,8 +360,9 @@ class HRNetProgram:
                 for op in self._ops]
 
     def macs_per_image(self):
-        return sum(op["ks"] ** 2 * op["cin"] * op["cout"] * op["hout"] * op["wout"]
-                   for op in self._ops if op["kind"] in (_lib.UDP_OP_STEM, _lib.UDP_OP_CONV, _lib.UDP_OP_STEM7))
+        return sum(op["ks"] ** 2 * op["cin"] * op["cout"] * op["hout"] * op["wout"] * (2 if op["kind"] == _lib.UDP_OP_BLOCK else 1)
+                   for op in self._ops
+                   if op["kind"] in (_lib.UDP_OP_STEM, _lib.UDP_OP_CONV, _lib.UDP_OP_STEM7, _lib.UDP_OP_BLOCK))
 
     def activation_elems_per_image(self):
         """Layer-wise algorithmic traffic: every op reads its inputs once and writes its output once."""
