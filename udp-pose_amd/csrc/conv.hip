@@ -257,8 +257,8 @@ __device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[MBW][NB], const unsigned
 }
 
 // MBW = 16-pixel blocks per wave (ceil(M/64)); NCHW = epilogue writes the fp32 NCHW network output.
-template <typename T, int KS, int STRIDE, int NB, int MBW, bool NCHW>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
+template <typename T, int KS, int STRIDE, int NB, int MBW, bool NCHW, int NW>
+__global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(const ConvParams p) {
   constexpr int CK = Tr<T>::CK;
   constexpr int ESZ = (int)sizeof(T);
   constexpr int BN = NB * 16;
@@ -314,8 +314,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
 #pragma unroll
   for (int i = 0; i < MAXG; ++i) {
     unsigned off = kOobOff;
-    if ((wave + 4 * i) * 16 < npix_in) {   // wave-uniform
-      const int row = (wave + 4 * i) * 16 + srow;
+    if ((wave + NW * i) * 16 < npix_in) {   // wave-uniform
+      const int row = (wave + NW * i) * 16 + srow;
       const int tmp = fdiv20(row, p.mIW);
       const int ix = row - (int)__umul24(tmp, IW);
       const int g = fdiv20(tmp, p.mIH);
@@ -334,14 +334,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     const int parts_left = (p.Cin - c * CK) / (16 / ESZ);  // 16-byte parts of this chunk that exist
 #pragma unroll
     for (int i = 0; i < MAXG; ++i) {
-      const int gidx = wave + 4 * i;
+      const int gidx = wave + NW * i;
       if (gidx < in_groups) {
         unsigned off = src_off[i] + coff;
         if (cut && (spart ^ swz(gidx * 16 + srow)) >= parts_left) off = kOobOff;
         blds16(r_in, off, sb + gidx * (16 * ROWB));
       }
     }
-    for (int gidx = wave; gidx < WGROUPS; gidx += 4) {
+    for (int gidx = wave; gidx < WGROUPS; gidx += NW) {
       const int wr = gidx * 16 + srow;
       const int tap = wr / BN;   // BN is a power of two
       const int rho = wr & (BN - 1);
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
   const int cbase = cb * BN + 4 * NB * kg;
 #pragma unroll
   for (int i = 0; i < MBW; ++i) {
-    const int m0 = (wave + 4 * i) * 16 + li;
+    const int m0 = (wave + NW * i) * 16 + li;
     const int m = m0 < M ? m0 : M - 1;
     const int g = fdiv20(m, p.mRT);
     const int rem = m - (int)__umul24(g, RT);
@@ -1121,17 +1121,17 @@ size_t conv_choose_tile(ConvParams& p, int ks, int stride, int dtype, int* nb_ou
   return lds(G, R, NB);
 }
 
-template <typename T, int KS, int STRIDE, int NB, int MBW, bool NCHW>
+template <typename T, int KS, int STRIDE, int NB, int MBW, bool NCHW, int NW>
 static int describe_one(const ConvParams& p, size_t lds, Launch* out) {
   static bool attr_set = false;
-  const void* kern = reinterpret_cast<const void*>(&conv_mfma_kernel<T, KS, STRIDE, NB, MBW, NCHW>);
+  const void* kern = reinterpret_cast<const void*>(&conv_mfma_kernel<T, KS, STRIDE, NB, MBW, NCHW, NW>);
   if (!attr_set) {
     UDP_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   out->fn = kern;
   out->grid = dim3(ceil_div(p.N, p.G) * p.tiles_y * p.tiles_x, p.CoutPad / (NB * 16));
-  out->block = dim3(256);
+  out->block = dim3(NW * 64);
   out->lds = (unsigned)lds;
   out->p = p;
   return UDP_OK;
@@ -1139,11 +1139,16 @@ static int describe_one(const ConvParams& p, size_t lds, Launch* out) {
 
 template <typename T, int KS, int STRIDE, int NB, bool NCHW>
 static int describe_mbw(const ConvParams& p, int mbw, size_t lds, Launch* out) {
+  // mbw = 16-pixel blocks per wave with 4 waves.  Tiles of more than 128 pixels run with 8 waves (two per
+  // SIMD, half the blocks each): the same LDS tile feeds twice the waves, which hides LDS / DMA latency
+  static const bool w8 = getenv("UDP_POSE_CONV_8W") != nullptr;
+  if (w8 && std::is_same<T, __bf16>::value && !NCHW && mbw >= 3)
+    return mbw == 3 ? describe_one<T, KS, STRIDE, NB, 2, NCHW, 8>(p, lds, out) : describe_one<T, KS, STRIDE, NB, 2, NCHW, 8>(p, lds, out);
   switch (mbw) {
-    case 1: return describe_one<T, KS, STRIDE, NB, 1, NCHW>(p, lds, out);
-    case 2: return describe_one<T, KS, STRIDE, NB, 2, NCHW>(p, lds, out);
-    case 3: return describe_one<T, KS, STRIDE, NB, 3, NCHW>(p, lds, out);
-    case 4: return describe_one<T, KS, STRIDE, NB, 4, NCHW>(p, lds, out);
+    case 1: return describe_one<T, KS, STRIDE, NB, 1, NCHW, 4>(p, lds, out);
+    case 2: return describe_one<T, KS, STRIDE, NB, 2, NCHW, 4>(p, lds, out);
+    case 3: return describe_one<T, KS, STRIDE, NB, 3, NCHW, 4>(p, lds, out);
+    case 4: return describe_one<T, KS, STRIDE, NB, 4, NCHW, 4>(p, lds, out);
   }
   return fail(UDP_ERR_UNSUPPORTED, "conv tile of %d pixel blocks per wave has no kernel", mbw);
 }
