@@ -106,9 +106,11 @@ def roofline(net, hp, steps, dtype):
     b = 2 * hp.n
     classes = {}
     for t, (name, kind, ks, stride, cin, cout, ho, wo) in zip(ms, desc):
-        key = {0: "stem", 2: "fuse_sum", 3: "stem7x7", 4: "maxpool", 5: "bilinear"}.get(
+        key = {0: "stem", 2: "fuse_sum", 3: "stem7x7", 4: "maxpool", 5: "bilinear", 10: "basic_block_c32"}.get(
             kind, "conv%dx%d_s%d_nb%d" % (ks, ks, stride, 4 if cout % 64 == 0 else 2))
         flops = 2.0 * ks * ks * cin * cout * ho * wo * b if kind in (0, 1, 3) else 0.0
+        if kind == 10:                                   # fused BasicBlock: two 3x3 convs
+            flops = 2 * 2.0 * 9 * cin * cout * ho * wo * b
         hin, win = ho * stride, wo * stride
         byts = (hin * win * cin * (4 if kind in (0, 3) else esz) + ho * wo * cout * esz) * b
         c = classes.setdefault(key, [0.0, 0.0, 0.0, 0])
@@ -122,7 +124,9 @@ def roofline(net, hp, steps, dtype):
     table = {k: {"ms": round(v[0], 4), "launches": v[3], "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 2) if v[0] > 0 else 0,
                  "gbs": round(v[2] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else 0} for k, v in classes.items()}
     traffic = None      # HBM bytes per launch from separate rocprofv3 --pmc passes (tools/pmc_by_op.py)
-    tfile = os.path.join(ROOT, "profiles", "r01b_traffic_%s.json" % dtype)
+    tfile = os.path.join(ROOT, "profiles", "r01f_traffic_%s.json" % dtype)
+    if not os.path.exists(tfile):
+        tfile = os.path.join(ROOT, "profiles", "r01b_traffic_%s.json" % dtype)
     if os.path.exists(tfile) and hp.n == 64 and hp.h == 256:
         with open(tfile) as f:
             tc = json.load(f)["classes"].get(dom)

@@ -16,7 +16,7 @@ def rows(d, counter):
     f = glob.glob(d + "/*/*counter_collection.csv")[0]
     out = []
     for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] == counter and any(k in r["Kernel_Name"] for k in ("conv_mfma_kernel", "stem_conv_kernel", "fuse_sum_kernel")):
+        if r["Counter_Name"] == counter and any(k in r["Kernel_Name"] for k in ("conv_mfma_", "basic_block_c32", "stem_conv_kernel", "fuse_sum_kernel")):
             out.append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
     out.sort()
     return [v for _, v in out]
@@ -35,7 +35,7 @@ def main():
     b = 128
     classes = {}
     for (name, kind, ks, st, cin, cout, ho, wo), f, w in zip(desc, fe, wr):
-        key = "stem" if kind == 0 else ("fuse_sum" if kind == 2 else "conv%dx%d_s%d_nb%d" % (ks, ks, st, 4 if cout > 32 else 2))
+        key = {0: "stem", 2: "fuse_sum", 10: "basic_block_c32"}.get(kind, "conv%dx%d_s%d_nb%d" % (ks, ks, st, 4 if cout % 64 == 0 else 2))
         alg = (ho * st * wo * st * cin * (4 if kind == 0 else esz) + ho * wo * cout * esz) * b
         c = classes.setdefault(key, dict(launches=0, fetch_bytes=0.0, write_bytes=0.0, algorithmic_in_out_bytes=0.0))
         c["launches"] += 1
