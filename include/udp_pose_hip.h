@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UDP_POSE_ABI_VERSION 9
+#define UDP_POSE_ABI_VERSION 10
 
 enum udp_status {
   UDP_OK = 0,
@@ -104,6 +104,9 @@ typedef struct udp_conv_op {
   int32_t n_wait;          /* cross-lane dependencies: this op starts after ops wait_op[0..n_wait) */
   int32_t wait_op[UDP_MAX_WAIT];
   int64_t w2_off, b2_off;  /* UDP_OP_BLOCK: the second conv's weights / bias in the blob */
+  int32_t group;           /* != 0: consecutive UDP_OP_CONV ops with the same group id are independent of each
+                              other (same-depth convs of different HRNet branches) and may share one launch */
+  int32_t reserved;
 } udp_conv_op;
 
 typedef struct udp_hrnet udp_hrnet; /* opaque */

@@ -334,3 +334,28 @@ def test_fused_basic_block_equals_the_two_conv_launches(h, w, monkeypatch):
     e_f = np.sqrt(((outs[True] - ref) ** 2).mean())
     e_u = np.sqrt(((outs[False] - ref) ** 2).mean())
     assert e_f < 1.15 * e_u + 1e-4, (e_f, e_u)
+
+
+def test_merged_branch_launches_equal_separate_launches(monkeypatch):
+    """bf16 graph mode: the same-depth convs of different branches run as ONE conv_mfma_multi launch
+    (hrnet.hip build_graph).  Per output element the accumulation order does not depend on the tile
+    choice, so the result equals the ungrouped program bit for bit; eager mode (per-op launches) too."""
+    extra = synth.scaled_extra(32, modules=(1, 2, 2), blocks=2)
+    sd = synth.synth_state_dict(extra, 17, "gaussian", seed=14)
+    x = torch.from_numpy(synth.synth_crops(5, 128, 96, seed=15))
+    ohrnet.hrnet_forward(sd, extra, x, calibrate=True)
+    outs = {}
+    for mode in ("grouped", "eager", "plain"):
+        if mode == "plain":
+            monkeypatch.setenv("UDP_POSE_NO_GROUPS", "1")
+        else:
+            monkeypatch.delenv("UDP_POSE_NO_GROUPS", raising=False)
+        net = MODELS["pose_hrnet"](_cfg(extra, 17, "gaussian"), is_train=False, dtype="bf16").load_state_dict(sd).to("cuda")
+        net.use_graph = mode != "eager"
+        groups = [o.group for o in net.program(128, 96).ops_array()]
+        assert (max(groups) > 0) == (mode != "plain")
+        outs[mode] = net.raw_forward(x.cuda(), flip_test=True).clone()
+        outs[mode + "2"] = net.raw_forward(x.cuda(), flip_test=True).clone()        # graph replay
+    torch.testing.assert_close(outs["grouped"], outs["plain"], rtol=0, atol=0)
+    torch.testing.assert_close(outs["grouped2"], outs["plain"], rtol=0, atol=0)
+    torch.testing.assert_close(outs["eager"], outs["plain"], rtol=0, atol=0)

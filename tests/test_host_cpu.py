@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libudp_pose_hip.so does not export %s" % name
     assert declared == set(_lib.EXPORTS)
-    assert lib.udp_abi_version() == _lib.ABI_VERSION == 9
+    assert lib.udp_abi_version() == _lib.ABI_VERSION == 10
 
 
 def test_argument_validation_without_gpu():
@@ -147,3 +147,25 @@ def test_psa_program_emission():
     with pytest.raises(ValueError):
         sd48 = synth.synth_state_dict(synth.scaled_extra(48, modules=(1, 1, 1), blocks=1), 17, "gaussian", seed=6, psa=True)
         hrnet_plan.HRNetProgram(sd48, synth.scaled_extra(48, modules=(1, 1, 1), blocks=1), 128, 96, "f32")
+
+
+def test_launch_groups_are_independent():
+    """Ops sharing a group id are merged into one launch: no member may read or overwrite what another
+    member writes, and a buffer a member reads for the last time is not recycled inside the group."""
+    sd = synth.synth_state_dict(synth.W32_EXTRA, 17, "gaussian", seed=0)
+    prog = hrnet_plan.HRNetProgram(sd, synth.W32_EXTRA, 256, 192, "bf16")
+    ops = prog.ops_array()
+    groups = {}
+    for i, o in enumerate(ops):
+        if o.group:
+            groups.setdefault(o.group, []).append(i)
+    assert len(groups) == 56 and sorted(set(map(len, groups.values()))) == [2, 3]
+    for g, idx in groups.items():
+        assert idx == list(range(idx[0], idx[0] + len(idx)))                      # consecutive
+        outs = [ops[i].out_buf for i in idx]
+        assert len(set(outs)) == len(outs)
+        for i in idx:
+            o = ops[i]
+            assert o.kind == _lib.UDP_OP_CONV and o.ks == 3 and o.stride == 1 and o.n_up == 0
+            reads = {o.in_buf, o.res_buf} - {_lib.UDP_BUF_NONE}
+            assert not (reads & (set(outs) - {o.out_buf})), (g, i)

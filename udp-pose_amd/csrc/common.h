@@ -58,14 +58,23 @@ struct ConvParams {
   int flip_from;         // stem only: images >= flip_from read image (n - flip_from) mirrored in x
 };
 
+// Kernel argument of conv_mfma_multi: up to 4 independent convs in one launch (flat block index ->
+// sub-problem j, tile, cout block).
+struct ConvMulti {
+  ConvParams p[4];
+  unsigned start[5];      // first flat block of sub-problem j; unused entries 0xFFFFFFFF, start[4] = total
+  unsigned tiles[4];      // tiles (grid.x) of sub-problem j
+};
+
 }  // namespace udp
 
 namespace udp {
 // One kernel launch, described once and then either enqueued on a stream or added to a hipGraph.
 struct Launch {
-  const void* fn;
+  const void* fn = nullptr;
   dim3 grid, block;
-  unsigned lds;
+  unsigned lds = 0;
+  int groupable = 0;   // conv described by describe_conv_grouped: may be merged with its group siblings
   ConvParams p;
 };
 }  // namespace udp

@@ -258,7 +258,7 @@ __device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[MBW][NB], const unsigned
 
 // MBW = 16-pixel blocks per wave (ceil(M/64)); NCHW = epilogue writes the fp32 NCHW network output.
 template <typename T, int KS, int STRIDE, int NB, int MBW, bool NCHW, int NW>
-__global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(const ConvParams p) {
+__device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int tile_id, const int cb) {
   constexpr int CK = Tr<T>::CK;
   constexpr int ESZ = (int)sizeof(T);
   constexpr int BN = NB * 16;
@@ -274,14 +274,13 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(const ConvParams p) 
   const int li = lane & 15;
   const int kg = lane >> 4;
 
-  int t = blockIdx.x;   // wave-uniform tile decode
+  int t = tile_id;   // wave-uniform tile decode
   const int tx = t % p.tiles_x;
   t /= p.tiles_x;
   const int ty = t % p.tiles_y;
   const int n0 = (t / p.tiles_y) * p.G;
   const int y0 = ty * p.R;
   const int x0 = tx * p.TW;
-  const int cb = blockIdx.y;
 
   const int IH = p.IH, IW = p.IW;
   const int npix_in = p.G * IH * IW;
@@ -461,6 +460,24 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(const ConvParams p) 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   UDP_STAMP(7);
 #endif
+}
+
+template <typename T, int KS, int STRIDE, int NB, int MBW, bool NCHW, int NW>
+__global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(const ConvParams p) {
+  conv_mfma_body<T, KS, STRIDE, NB, MBW, NCHW, NW>(p, blockIdx.x, blockIdx.y);
+}
+
+// Horizontal fusion: up to 4 independent convs (the same-depth convs of different HRNet branches, which
+// share the instantiation) in ONE launch.  Concurrent streams / graph branches do not overlap such
+// launches on this GPU (measured), and each launch costs ~3.7 us of ramp-up and drain at batch 64; one
+// grid covering all of them also evens out the per-launch workgroup-count quantisation.
+template <typename T, int KS, int STRIDE, int NB, int MBW, int NW>
+__global__ __launch_bounds__(NW * 64) void conv_mfma_multi(const ConvMulti m) {
+  const unsigned b = blockIdx.x;
+  const int j = (b >= m.start[1]) + (b >= m.start[2]) + (b >= m.start[3]);
+  const unsigned r = b - m.start[j];
+  const unsigned cb = r / m.tiles[j];
+  conv_mfma_body<T, KS, STRIDE, NB, MBW, false, NW>(m.p[j], (int)(r - cb * m.tiles[j]), (int)cb);
 }
 
 // Persistent form of conv_mfma_kernel for layers whose Cin fits ONE 64-byte chunk (bf16 Cin = 32:
@@ -1063,7 +1080,7 @@ static int largest_divisor_leq(int n, int lim) {
 }
 
 // Picks the (G, R, TW) tile and NB for one conv; returns the dynamic LDS bytes.
-size_t conv_choose_tile(ConvParams& p, int ks, int stride, int dtype, int* nb_out) {
+size_t conv_choose_tile(ConvParams& p, int ks, int stride, int dtype, int* nb_out, bool grouped = false) {
   // tuning knobs (environment overrides are a measurement aid for tools/profile_layers.py)
   auto knob = [](const char* name, long dflt) {
     const char* v = getenv(name);
@@ -1085,7 +1102,7 @@ size_t conv_choose_tile(ConvParams& p, int ks, int stride, int dtype, int* nb_ou
     if (G < 1) G = 1;
     if (G > p.N) G = p.N;
   }
-  int NB = (p.CoutPad % 64 == 0) ? 4 : 2;
+  int NB = (p.CoutPad % 64 == 0 && !grouped) ? 4 : 2;
   auto npix = [&](int g, int r) { return g * ((r - 1) * stride + ks) * ((TW - 1) * stride + ks); };
   auto lds = [&](int g, int r, int nb) {
     return (size_t)(((npix(g, r) + 15) / 16) * 16 + ks * ks * nb * 16) * ROWB * nstage;
@@ -1094,7 +1111,7 @@ size_t conv_choose_tile(ConvParams& p, int ks, int stride, int dtype, int* nb_ou
     return (long)ceil_div(p.N, g) * ceil_div(p.Hout, r) * ceil_div(p.Wout, TW) * (p.CoutPad / (nb * 16));
   };
   // small problems: trade tile size for workgroups (256 CUs, aim for >= 2 per CU)
-  const long kMinWgs = knob("UDP_POSE_MINWGS", 512);
+  const long kMinWgs = grouped ? 0 : knob("UDP_POSE_MINWGS", 512);   // a grouped launch fills the chip with its siblings
   if (wgs(G, R, NB) < kMinWgs && NB == 4) NB = 2;
   while (wgs(G, R, NB) < kMinWgs && G > 1) G = (G + 1) / 2;
   const size_t kLimit = (size_t)knob("UDP_POSE_LDS_KB", 76) * 1024;   // 76 KB: two workgroups per CU
@@ -1290,12 +1307,71 @@ int describe_conv(ConvParams p, int dtype, int ks, int stride, Launch* out) {
   if (p.CoutPad % (nb * 16) != 0)
     return fail(UDP_ERR_UNSUPPORTED, "conv CoutPad=%d is not a multiple of %d", p.CoutPad, nb * 16);
   const int mbw = ceil_div(ceil_div(p.G * p.R * p.TW, 16), 4);
+  if (getenv("UDP_POSE_DEBUG_TILES"))
+    fprintf(stderr, "conv k%d s%d %dx%d C%d->%d: G=%d R=%d TW=%d NB=%d mbw=%d lds=%zu wgs=%d\n", ks, stride, p.Hout, p.Wout, p.Cin,
+            p.Cout, p.G, p.R, p.TW, nb, mbw, lds, p.ntiles * (p.CoutPad / (nb * 16)));
   if (dtype == UDP_BF16 && getenv("UDP_POSE_NO_PERSIST") == nullptr) {
     const int rc = describe_persist(p, ks, stride, nb, mbw, out);
     if (rc <= 0) return rc;
   }
   if (dtype == UDP_F32) return describe_conv_t<float>(p, ks, stride, nb, mbw, lds, out);
   return describe_conv_t<__bf16>(p, ks, stride, nb, mbw, lds, out);
+}
+
+// A conv that will share one launch with the same-depth convs of other branches (hrnet.hip merges them
+// into a conv_mfma_multi node): every member uses the instantiation <bf16, 3, 1, NB=2, MBW=4, 4 waves>.
+// Returns 1 when the conv does not qualify (the caller falls back to describe_conv).
+int describe_conv_grouped(ConvParams p, int dtype, int ks, int stride, Launch* out) {
+  if (dtype != UDP_BF16 || ks != 3 || stride != 1 || p.out_nchw_f32 || p.nup || p.Cin % 32 || p.Cout % 32) return 1;
+  if ((size_t)p.N * p.Hin * p.Win * p.in_pitch * 2 >= 0x7FFF0000u || (p.in_coff * 2) % 16 || (p.in_pitch * 2) % 16 ||
+      (p.out_coff * 2) % 16 || (p.out_pitch * 2) % 16 || (p.res && ((p.res_coff * 2) % 16 || (p.res_pitch * 2) % 16)) || p.N >= 2048)
+    return 1;
+  int nb = 2;
+  const size_t lds = conv_choose_tile(p, ks, stride, dtype, &nb, true);
+  if (nb != 2 || p.G * p.R * p.TW > 256) return 1;
+  if (getenv("UDP_POSE_DEBUG_TILES"))
+    fprintf(stderr, "grouped conv %dx%d C%d->%d: G=%d R=%d TW=%d NB=2 lds=%zu wgs=%d\n", p.Hout, p.Wout, p.Cin, p.Cout, p.G, p.R,
+            p.TW, lds, p.ntiles * (p.CoutPad / 32));
+  const int mbw = ceil_div(ceil_div(p.G * p.R * p.TW, 16), 4);
+  const bool m3 = mbw <= 3 && getenv("UDP_POSE_MULTI_MBW4") == nullptr;
+  const int rc = m3 ? describe_one<__bf16, 3, 1, 2, 3, false, 4>(p, lds, out) : describe_one<__bf16, 3, 1, 2, 4, false, 4>(p, lds, out);
+  if (rc) return rc;
+  out->groupable = m3 ? 3 : 4;      // pixel blocks per wave of the instantiation that can run it
+  return UDP_OK;
+}
+
+// Kernel + attribute for a merged launch of `n` groupable convs; fills the kernel argument.
+int describe_multi(const Launch* members, int n, ConvMulti* m, Launch* out) {
+  static bool attr_set = false;
+  const void* kern3 = reinterpret_cast<const void*>(&conv_mfma_multi<__bf16, 3, 1, 2, 3, 4>);
+  const void* kern4 = reinterpret_cast<const void*>(&conv_mfma_multi<__bf16, 3, 1, 2, 4, 4>);
+  if (!attr_set) {
+    UDP_HIP_CHECK(hipFuncSetAttribute(kern3, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    UDP_HIP_CHECK(hipFuncSetAttribute(kern4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  if (n < 2 || n > 4) return fail(UDP_ERR_ARG, "describe_multi: %d members", n);
+  int mbw = 3;
+  for (int j = 0; j < n; ++j)
+    if (members[j].groupable > mbw) mbw = members[j].groupable;
+  const void* kern = mbw == 3 ? kern3 : kern4;
+  memset(m, 0, sizeof(*m));
+  unsigned total = 0, lds = 0;
+  for (int j = 0; j < n; ++j) {
+    m->p[j] = members[j].p;
+    m->start[j] = total;
+    m->tiles[j] = members[j].grid.x;
+    total += members[j].grid.x * members[j].grid.y;
+    if (members[j].lds > lds) lds = members[j].lds;
+  }
+  for (int j = n; j < 5; ++j) m->start[j] = j < 4 ? 0xFFFFFFFFu : total;
+  for (int j = n; j < 4; ++j) m->tiles[j] = 1;
+  out->fn = kern;
+  out->grid = dim3(total);
+  out->block = dim3(256);
+  out->lds = lds;
+  out->groupable = 0;
+  return UDP_OK;
 }
 
 int describe_stem(const ConvParams& p, int dtype, Launch* out) {

@@ -16,6 +16,8 @@ int describe_maxpool(const ConvParams& p, int dtype, Launch* out);
 int describe_bilinear(const ConvParams& p, int dtype, Launch* out);
 int describe_psa(const ConvParams& p, int dtype, int kind, Launch* out);
 int describe_block(ConvParams p, int dtype, Launch* out);
+int describe_conv_grouped(ConvParams p, int dtype, int ks, int stride, Launch* out);
+int describe_multi(const Launch* members, int n, ConvMulti* m, Launch* out);
 int run_launch(const Launch& l, hipStream_t s);
 }  // namespace udp
 
@@ -287,7 +289,9 @@ static int describe_all(const udp_hrnet* h, const float* in, int n, int flip, ch
       case UDP_OP_FUSE: rc = describe_fuse(p, h->dtype, &ls[i]); break;
       case UDP_OP_MAXPOOL: rc = describe_maxpool(p, h->dtype, &ls[i]); break;
       case UDP_OP_BILINEAR: rc = describe_bilinear(p, h->dtype, &ls[i]); break;
-      default: rc = describe_conv(p, h->dtype, o.ks, o.stride, &ls[i]);
+      default:
+        rc = o.group != 0 && getenv("UDP_POSE_NO_GROUPS") == nullptr ? describe_conv_grouped(p, h->dtype, o.ks, o.stride, &ls[i]) : 1;
+        if (rc == 1) rc = describe_conv(p, h->dtype, o.ks, o.stride, &ls[i]);
     }
     if (rc) return rc;
   }
@@ -331,34 +335,60 @@ static int enqueue_all(udp_hrnet* h, const std::vector<Launch>& L, hipStream_t s
 // the planner's cross-lane dependencies, so independent HRNet branches overlap on the GPU.
 static int build_graph(udp_hrnet* h, const std::vector<Launch>& L, hipGraph_t* graph, hipGraphExec_t* exec) {
   UDP_HIP_CHECK(hipGraphCreate(graph, 0));
-  std::vector<hipGraphNode_t> node(L.size());
+  // launch list: runs of groupable convs with the same group id become one conv_mfma_multi launch
+  struct Node { size_t first; int n; };
+  std::vector<Node> nodes;
+  bool grouped = false;
+  for (size_t i = 0; i < L.size();) {
+    int n = 1;
+    if (L[i].groupable && h->ops[i].group != 0)
+      while (n < 4 && i + n < L.size() && L[i + n].groupable && h->ops[i + n].group == h->ops[i].group) ++n;
+    nodes.push_back({i, n});
+    grouped |= n > 1;
+    i += n;
+  }
+  std::vector<hipGraphNode_t> node(nodes.size());
+  std::vector<int> node_of_op(L.size(), -1);
   int last_on_lane[UDP_MAX_LANES] = {-1, -1, -1, -1};
-  const bool serial = getenv("UDP_POSE_SERIAL") != nullptr;   // debugging aid: one chain, no branch overlap
-  for (size_t i = 0; i < L.size(); ++i) {
+  // merged launches span lanes: one chain (branch overlap through graph edges bought nothing anyway)
+  const bool serial = grouped || getenv("UDP_POSE_SERIAL") != nullptr;
+  for (size_t k = 0; k < nodes.size(); ++k) {
+    const size_t i = nodes[k].first;
     const udp_conv_op& o = h->ops[i];
     std::vector<hipGraphNode_t> deps;
     if (serial) {
-      if (i) deps.push_back(node[i - 1]);
+      if (k) deps.push_back(node[k - 1]);
     } else {
       if (last_on_lane[o.lane] >= 0) deps.push_back(node[last_on_lane[o.lane]]);
-      for (int k = 0; k < o.n_wait; ++k) deps.push_back(node[o.wait_op[k]]);
+      for (int w = 0; w < o.n_wait; ++w) deps.push_back(node[node_of_op[o.wait_op[w]]]);
     }
     ConvParams p = L[i].p;
-    void* args[] = {&p};
+    ConvMulti m;
+    Launch ml = L[i];
+    void* args[1] = {&p};
+    if (nodes[k].n > 1) {
+      const int rc = describe_multi(&L[i], nodes[k].n, &m, &ml);
+      if (rc) {
+        (void)hipGraphDestroy(*graph);
+        return rc;
+      }
+      args[0] = &m;
+    }
     hipKernelNodeParams kp;
     memset(&kp, 0, sizeof(kp));
-    kp.func = const_cast<void*>(L[i].fn);
-    kp.gridDim = L[i].grid;
-    kp.blockDim = L[i].block;
-    kp.sharedMemBytes = L[i].lds;
+    kp.func = const_cast<void*>(ml.fn);
+    kp.gridDim = ml.grid;
+    kp.blockDim = ml.block;
+    kp.sharedMemBytes = ml.lds;
     kp.kernelParams = args;
     kp.extra = nullptr;
-    hipError_t e = hipGraphAddKernelNode(&node[i], *graph, deps.data(), deps.size(), &kp);
+    hipError_t e = hipGraphAddKernelNode(&node[k], *graph, deps.data(), deps.size(), &kp);
     if (e != hipSuccess) {
       (void)hipGraphDestroy(*graph);
       return fail(UDP_ERR_HIP, "hipGraphAddKernelNode(op %zu): %s", i, hipGetErrorString(e));
     }
-    last_on_lane[o.lane] = (int)i;
+    for (int j = 0; j < nodes[k].n; ++j) node_of_op[i + j] = (int)k;
+    last_on_lane[o.lane] = (int)k;
   }
   hipError_t e = hipGraphInstantiate(exec, *graph, nullptr, nullptr, 0);
   if (e != hipSuccess) {

@@ -56,6 +56,8 @@ class HRNetProgram:
         self.dtype = dtype
         self.in_h, self.in_w = in_h, in_w
         self.fuse_blocks = os.environ.get("UDP_POSE_NO_BLOCK_FUSION") is None
+        self.group_convs = dtype == "bf16" and os.environ.get("UDP_POSE_NO_GROUPS") is None
+        self._groups = 0
         self._tensors = []
         self._ops = []          # dicts with _T references
         self._blob = []         # list of (offset, np.ndarray uint8)
@@ -105,7 +107,7 @@ class HRNetProgram:
         self._tensors.append(t)
         return t
 
-    def _conv(self, x, conv, bn, stride=1, relu=True, res=None, ups=(), to_output=False):
+    def _conv(self, x, conv, bn, stride=1, relu=True, res=None, ups=(), to_output=False, group=0):
         w_off, b_off, cout, cin, ks, cout_pad = self._pack_conv(conv, bn)
         if cin != x.c:
             raise ValueError("%s: weight expects %d input channels, tensor has %d" % (conv, cin, x.c))
@@ -115,8 +117,21 @@ class HRNetProgram:
         out = None if to_output else self._new(cout, ho, wo)
         self._ops.append(dict(kind=_lib.UDP_OP_CONV, ks=ks, stride=stride, relu=int(relu), cin=cin, cout=cout,
                               cout_pad=cout_pad, hin=x.h, win=x.w, hout=ho, wout=wo, inp=x, out=out, res=res,
-                              ups=list(ups), w_off=w_off, b_off=b_off, name=conv))
+                              ups=list(ups), w_off=w_off, b_off=b_off, name=conv, group=group))
         return out
+
+    def _next_group(self):
+        self._groups += 1
+        return self._groups
+
+    def _basic_block(self, x, q):
+        """BasicBlock.forward (pose_hrnet.py:43-59; PSA variant pose_hrnet_psa.py:37,49)."""
+        if self._can_fuse_block(x, q):
+            return self._block(x, q)
+        t = self._conv(x, q + ".conv1", q + ".bn1")
+        if (q + ".deattn.conv_q_right.weight") in self.sd:
+            t = self._psa(t, q + ".deattn")
+        return self._conv(t, q + ".conv2", q + ".bn2", res=x)
 
     def _can_fuse_block(self, x, q):
         """The fused BasicBlock kernel (csrc/conv.hip basic_block_c32_kernel): bf16, 32 channels, rows in
@@ -221,16 +236,28 @@ class HRNetProgram:
     def _module(self, xs, p, num_blocks, last):
         nb = len(xs)
         xs = list(xs)
-        for b in range(nb):
-            for k in range(num_blocks[b]):
-                q = "%s.branches.%d.%d" % (p, b, k)
-                if self._can_fuse_block(xs[b], q):
-                    xs[b] = self._block(xs[b], q)
-                    continue
-                t = self._conv(xs[b], q + ".conv1", q + ".bn1")
-                if (q + ".deattn.conv_q_right.weight") in self.sd:       # pose_hrnet_psa.py:37,49
-                    t = self._psa(t, q + ".deattn")
-                xs[b] = self._conv(t, q + ".conv2", q + ".bn2", res=xs[b])
+        if self.group_convs and len(set(num_blocks[:nb])) == 1:
+            # block-major order: conv1 of block k of every branch, then conv2 of every branch.  The convs of
+            # one such row are independent; those the executor can merge carry a common group id
+            for k in range(num_blocks[0]):
+                qs = ["%s.branches.%d.%d" % (p, b, k) for b in range(nb)]
+                plain = [b for b in range(nb) if not self._can_fuse_block(xs[b], qs[b])
+                         and (qs[b] + ".deattn.conv_q_right.weight") not in self.sd]
+                gid = (self._next_group(), self._next_group()) if len(plain) > 1 else (0, 0)
+                mids = {}
+                for b in range(nb):
+                    if b in plain:
+                        mids[b] = self._conv(xs[b], qs[b] + ".conv1", qs[b] + ".bn1", group=gid[0])
+                for b in range(nb):
+                    if b in plain:
+                        xs[b] = self._conv(mids[b], qs[b] + ".conv2", qs[b] + ".bn2", res=xs[b], group=gid[1])
+                for b in range(nb):
+                    if b not in plain:
+                        xs[b] = self._basic_block(xs[b], qs[b])
+        else:
+            for b in range(nb):
+                for k in range(num_blocks[b]):
+                    xs[b] = self._basic_block(xs[b], "%s.branches.%d.%d" % (p, b, k))
         n_out = 1 if last else nb
         outs = []
         for i in range(n_out):
@@ -291,6 +318,7 @@ class HRNetProgram:
         free = {}             # elems -> [(buffer id, previous tenant tensor id)]
         self.buf_elems = []
         phys = {}
+        pending = []
         for idx, op in enumerate(self._ops):
             deps = set()
             for t in [op["inp"], op["res"]] + [u for u, _ in op["ups"]]:
@@ -320,10 +348,18 @@ class HRNetProgram:
             if len(cross) > _lib.MAX_WAIT:
                 raise RuntimeError("op %s has %d cross-lane dependencies (max %d)" % (op["name"], len(cross), _lib.MAX_WAIT))
             op["wait"] = cross
+            # members of a launch group run concurrently: a buffer one of them reads for the last time
+            # must not be handed to a later member of the same group
+            g = op.get("group", 0)
+            nxt = self._ops[idx + 1].get("group", 0) if idx + 1 < len(self._ops) else 0
             for t in [op["inp"], op["res"]] + [u for u, _ in op["ups"]]:
                 if t is not None and last_use.get(t.id) == idx and t.id in phys:
-                    free.setdefault(t.elems, []).append((phys[t.id], t.id))
+                    pending.append((t.elems, phys[t.id], t.id))
                     last_use[t.id] = -1
+            if g == 0 or nxt != g:
+                for elems, b, tid in pending:
+                    free.setdefault(elems, []).append((b, tid))
+                pending = []
         self._phys = phys
 
     # ------------------------------------------------------------------ output
@@ -337,7 +373,7 @@ class HRNetProgram:
             o.in_buf = _lib.UDP_BUF_NONE if op["inp"] is None else self._phys[op["inp"].id]
             o.out_buf = _lib.UDP_BUF_OUTPUT if op["out"] is None else self._phys[op["out"].id]
             o.res_buf = _lib.UDP_BUF_NONE if op["res"] is None else self._phys[op["res"].id]
-            for f in ("in_coff", "in_pitch", "out_coff", "out_pitch", "res_coff", "res_pitch", "w2_off", "b2_off"):
+            for f in ("in_coff", "in_pitch", "out_coff", "out_pitch", "res_coff", "res_pitch", "w2_off", "b2_off", "group"):
                 setattr(o, f, op.get(f, 0))
             o.lane = op["lane"]
             o.n_wait = len(op["wait"])
