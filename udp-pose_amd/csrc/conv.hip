@@ -1322,7 +1322,7 @@ int describe_conv(ConvParams p, int dtype, int ks, int stride, Launch* out) {
 // into a conv_mfma_multi node): every member uses the instantiation <bf16, 3, 1, NB=2, MBW=4, 4 waves>.
 // Returns 1 when the conv does not qualify (the caller falls back to describe_conv).
 int describe_conv_grouped(ConvParams p, int dtype, int ks, int stride, Launch* out) {
-  if (dtype != UDP_BF16 || ks != 3 || stride != 1 || p.out_nchw_f32 || p.nup || p.Cin % 32 || p.Cout % 32) return 1;
+  if (dtype != UDP_BF16 || (ks != 3 && ks != 1) || stride != 1 || p.out_nchw_f32 || p.nup || p.Cin % 32 || p.Cout % 32) return 1;
   if ((size_t)p.N * p.Hin * p.Win * p.in_pitch * 2 >= 0x7FFF0000u || (p.in_coff * 2) % 16 || (p.in_pitch * 2) % 16 ||
       (p.out_coff * 2) % 16 || (p.out_pitch * 2) % 16 || (p.res && ((p.res_coff * 2) % 16 || (p.res_pitch * 2) % 16)) || p.N >= 2048)
     return 1;
@@ -1334,27 +1334,35 @@ int describe_conv_grouped(ConvParams p, int dtype, int ks, int stride, Launch* o
             p.TW, lds, p.ntiles * (p.CoutPad / 32));
   const int mbw = ceil_div(ceil_div(p.G * p.R * p.TW, 16), 4);
   const bool m3 = mbw <= 3 && getenv("UDP_POSE_MULTI_MBW4") == nullptr;
-  const int rc = m3 ? describe_one<__bf16, 3, 1, 2, 3, false, 4>(p, lds, out) : describe_one<__bf16, 3, 1, 2, 4, false, 4>(p, lds, out);
+  int rc;
+  if (ks == 3)
+    rc = m3 ? describe_one<__bf16, 3, 1, 2, 3, false, 4>(p, lds, out) : describe_one<__bf16, 3, 1, 2, 4, false, 4>(p, lds, out);
+  else
+    rc = m3 ? describe_one<__bf16, 1, 1, 2, 3, false, 4>(p, lds, out) : describe_one<__bf16, 1, 1, 2, 4, false, 4>(p, lds, out);
   if (rc) return rc;
-  out->groupable = m3 ? 3 : 4;      // pixel blocks per wave of the instantiation that can run it
+  out->groupable = ks * 10 + (m3 ? 3 : 4);      // kernel size, pixel blocks per wave of the instantiation that can run it
   return UDP_OK;
 }
 
 // Kernel + attribute for a merged launch of `n` groupable convs; fills the kernel argument.
 int describe_multi(const Launch* members, int n, ConvMulti* m, Launch* out) {
   static bool attr_set = false;
-  const void* kern3 = reinterpret_cast<const void*>(&conv_mfma_multi<__bf16, 3, 1, 2, 3, 4>);
-  const void* kern4 = reinterpret_cast<const void*>(&conv_mfma_multi<__bf16, 3, 1, 2, 4, 4>);
+  const void* kerns[4] = {reinterpret_cast<const void*>(&conv_mfma_multi<__bf16, 3, 1, 2, 3, 4>),
+                          reinterpret_cast<const void*>(&conv_mfma_multi<__bf16, 3, 1, 2, 4, 4>),
+                          reinterpret_cast<const void*>(&conv_mfma_multi<__bf16, 1, 1, 2, 3, 4>),
+                          reinterpret_cast<const void*>(&conv_mfma_multi<__bf16, 1, 1, 2, 4, 4>)};
   if (!attr_set) {
-    UDP_HIP_CHECK(hipFuncSetAttribute(kern3, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    UDP_HIP_CHECK(hipFuncSetAttribute(kern4, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    for (const void* k : kerns) UDP_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   if (n < 2 || n > 4) return fail(UDP_ERR_ARG, "describe_multi: %d members", n);
+  const int ks = members[0].groupable / 10;
   int mbw = 3;
-  for (int j = 0; j < n; ++j)
-    if (members[j].groupable > mbw) mbw = members[j].groupable;
-  const void* kern = mbw == 3 ? kern3 : kern4;
+  for (int j = 0; j < n; ++j) {
+    if (members[j].groupable / 10 != ks) return fail(UDP_ERR_ARG, "describe_multi: members of different kernel sizes");
+    if (members[j].groupable % 10 > mbw) mbw = members[j].groupable % 10;
+  }
+  const void* kern = kerns[(ks == 3 ? 0 : 2) + (mbw == 3 ? 0 : 1)];
   memset(m, 0, sizeof(*m));
   unsigned total = 0, lds = 0;
   for (int j = 0; j < n; ++j) {

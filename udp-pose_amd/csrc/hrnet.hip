@@ -342,7 +342,7 @@ static int build_graph(udp_hrnet* h, const std::vector<Launch>& L, hipGraph_t* g
   for (size_t i = 0; i < L.size();) {
     int n = 1;
     if (L[i].groupable && h->ops[i].group != 0)
-      while (n < 4 && i + n < L.size() && L[i + n].groupable && h->ops[i + n].group == h->ops[i].group) ++n;
+      while (n < 4 && i + n < L.size() && L[i + n].groupable / 10 == L[i].groupable / 10 && h->ops[i + n].group == h->ops[i].group) ++n;
     nodes.push_back({i, n});
     grouped |= n > 1;
     i += n;

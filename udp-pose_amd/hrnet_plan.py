@@ -260,11 +260,17 @@ class HRNetProgram:
                     xs[b] = self._basic_block(xs[b], "%s.branches.%d.%d" % (p, b, k))
         n_out = 1 if last else nb
         outs = []
-        for i in range(n_out):
-            ups = []
-            for j in range(i + 1, nb):
+        # the 1x1 convs of all j > i terms only read the branch outputs: emitted first, in launch groups of <= 4
+        pairs = [(i, j) for i in range(n_out) for j in range(i + 1, nb)]
+        up_terms = {i: [] for i in range(n_out)}
+        for c0 in range(0, len(pairs), 4):
+            chunk = pairs[c0:c0 + 4]
+            gid = self._next_group() if self.group_convs and len(chunk) > 1 else 0
+            for i, j in chunk:
                 q = "%s.fuse_layers.%d.%d" % (p, i, j)
-                ups.append((self._conv(xs[j], q + ".0", q + ".1", relu=False), j - i))
+                up_terms[i].append((self._conv(xs[j], q + ".0", q + ".1", relu=False, group=gid), j - i))
+        for i in range(n_out):
+            ups = up_terms[i]
             if i == 0:
                 if last:
                     outs.append(self._conv(xs[0], "%s.fuse_layers.0.0.0" % p, None, ups=ups))
