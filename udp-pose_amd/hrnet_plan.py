@@ -245,12 +245,11 @@ class HRNetProgram:
                          and (qs[b] + ".deattn.conv_q_right.weight") not in self.sd]
                 gid = (self._next_group(), self._next_group()) if len(plain) > 1 else (0, 0)
                 mids = {}
-                for b in range(nb):
-                    if b in plain:
-                        mids[b] = self._conv(xs[b], qs[b] + ".conv1", qs[b] + ".bn1", group=gid[0])
-                for b in range(nb):
-                    if b in plain:
-                        xs[b] = self._conv(mids[b], qs[b] + ".conv2", qs[b] + ".bn2", res=xs[b], group=gid[1])
+                order = list(reversed(plain)) if os.environ.get("UDP_POSE_GROUP_FWD") is None else plain
+                for b in order:            # deepest-K members first: their workgroups run longest
+                    mids[b] = self._conv(xs[b], qs[b] + ".conv1", qs[b] + ".bn1", group=gid[0])
+                for b in order:
+                    xs[b] = self._conv(mids[b], qs[b] + ".conv2", qs[b] + ".bn2", res=xs[b], group=gid[1])
                 for b in range(nb):
                     if b not in plain:
                         xs[b] = self._basic_block(xs[b], qs[b])
@@ -262,6 +261,8 @@ class HRNetProgram:
         outs = []
         # the 1x1 convs of all j > i terms only read the branch outputs: emitted first, in launch groups of <= 4
         pairs = [(i, j) for i in range(n_out) for j in range(i + 1, nb)]
+        if os.environ.get("UDP_POSE_GROUP_FWD") is None:
+            pairs.sort(key=lambda ij: (-ij[1], ij[0]))          # deepest-K (lowest-resolution source) first
         up_terms = {i: [] for i in range(n_out)}
         for c0 in range(0, len(pairs), 4):
             chunk = pairs[c0:c0 + 4]
