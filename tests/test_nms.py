@@ -62,3 +62,17 @@ def test_hip_rescore_and_nms_whole_evaluation():
         np.testing.assert_allclose([d["score"] for d in got[im]], sc[keep], rtol=1e-12)
         n_kept += len(keep)
     assert 0 < n_kept < p
+
+
+def test_coco_result_records(tmp_path):
+    """coco.py:397-428 record format, restated from the text (evaluate() itself needs pycocotools)."""
+    import json
+    from udp_pose_amd import nms as u_nms
+    kp = np.arange(51, dtype=np.float32).reshape(17, 3)
+    kept = {7: [{"keypoints": kp, "center": np.array([1.5, 2.5]), "scale": np.array([0.5, 0.75]), "area": 3.0,
+                 "score": 0.25, "image": 7}], 9: []}
+    rec = u_nms.coco_keypoint_results(kept)
+    assert rec == [{"image_id": 7, "category_id": 1, "keypoints": [float(v) for v in range(51)], "score": 0.25,
+                    "center": [1.5, 2.5], "scale": [0.5, 0.75]}]
+    u_nms.write_coco_keypoint_results(kept, str(tmp_path / "r.json"))
+    assert json.load(open(tmp_path / "r.json")) == rec

@@ -73,3 +73,28 @@ def rescore_and_nms(preds, all_boxes, image_ids, in_vis_thre, oks_thre, device="
                     "scale": all_boxes[perm[a + k]][2:4], "area": all_boxes[perm[a + k]][4],
                     "score": scores[a + k], "image": im} for k in keep]
     return out
+
+
+def coco_keypoint_results(kept_by_image, cat_id=1):
+    """coco.py:397-428 (``_coco_keypoint_results_one_category_kernel``): the list ``json.dump``ed as the COCO
+    keypoint result file -- one record per kept person with the 3J flat keypoints as float64, the rescored
+    score, center and scale.  ``kept_by_image``: the dict returned by ``rescore_and_nms`` (or a list of
+    per-image lists like the reference's ``oks_nmsed_kpts``).  ``cat_id`` 1 = 'person' (coco.py:69-77)."""
+    groups = kept_by_image.values() if isinstance(kept_by_image, dict) else kept_by_image
+    out = []
+    for img_kpts in groups:
+        if len(img_kpts) == 0:
+            continue
+        for k in img_kpts:
+            kp = np.asarray(k["keypoints"], dtype=np.float64).reshape(-1)        # x, y, score per joint
+            out.append({"image_id": k["image"], "category_id": cat_id, "keypoints": [float(v) for v in kp],
+                        "score": float(k["score"]), "center": [float(v) for v in k["center"]],
+                        "scale": [float(v) for v in k["scale"]]})
+    return out
+
+
+def write_coco_keypoint_results(kept_by_image, res_file, cat_id=1):
+    """coco.py:369-395: ``json.dump(results, f, sort_keys=True, indent=4)``."""
+    import json
+    with open(res_file, "w") as f:
+        json.dump(coco_keypoint_results(kept_by_image, cat_id), f, sort_keys=True, indent=4)
