@@ -132,7 +132,7 @@ def roofline(net, hp, steps, dtype):
             tc = json.load(f)["classes"].get(dom)
         if tc:
             traffic = round(tc["hbm_bytes_per_launch"], 0)
-    return {"bound": "mfma", "kernel": "conv_mfma_kernel<%s> %s" % (dtype, dom), "achieved": round(achieved, 2),
+    return {"bound": "mfma", "kernel": "conv_mfma_kernel / conv_mfma_multi <%s> %s" % (dtype, dom), "achieved": round(achieved, 2),
             "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS[dtype], 4),
             "traffic": traffic, "traffic_source": os.path.basename(tfile) if traffic else None,
             "launches_per_step": cnt, "avg_launch_us": round(t_ms / cnt * 1e3, 2),

@@ -123,9 +123,10 @@ size_t udp_hrnet_workspace_bytes(const udp_hrnet* h, int n, int flip_test);
  * udp_flip_fuse).  use_graph != 0 replays a cached hipGraph of the launch sequence. */
 int udp_hrnet_forward(udp_hrnet* h, const float* in_nchw, int n, int flip_test, void* workspace,
                       size_t workspace_bytes, float* heatmaps_nchw, int use_graph, void* stream);
-/* Same launches as udp_hrnet_forward (eager, no graph) with a hipEvent pair around every op on
+/* Same launches as udp_hrnet_forward (eager, no graph) with a hipEvent pair around every launch on
  * `stream`; waits for completion and writes the elapsed milliseconds of op i to ms_per_op_host[i]
- * (udp_hrnet_num_launches entries).  Measurement aid for bench.py's roofline section. */
+ * (udp_hrnet_num_launches entries; the time of a merged launch -- ops sharing a `group` -- is split over
+ * its members in proportion to their FLOPs).  Measurement aid for bench.py's roofline section. */
 int udp_hrnet_profile(udp_hrnet* h, const float* in_nchw, int n, int flip_test, void* workspace,
                       size_t workspace_bytes, float* heatmaps_nchw, float* ms_per_op_host, void* stream);
 int udp_hrnet_destroy(udp_hrnet* h);

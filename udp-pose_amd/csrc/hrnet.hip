@@ -298,10 +298,52 @@ static int describe_all(const udp_hrnet* h, const float* in, int n, int flip, ch
   return UDP_OK;
 }
 
+// Launch list: runs of groupable convs with the same group id become one conv_mfma_multi launch.
+struct Node {
+  size_t first;
+  int n;
+};
+static std::vector<Node> make_nodes(const udp_hrnet* h, const std::vector<Launch>& L, bool* grouped) {
+  std::vector<Node> nodes;
+  *grouped = false;
+  for (size_t i = 0; i < L.size();) {
+    int n = 1;
+    if (L[i].groupable && h->ops[i].group != 0)
+      while (n < 4 && i + n < L.size() && L[i + n].groupable / 10 == L[i].groupable / 10 && h->ops[i + n].group == h->ops[i].group) ++n;
+    nodes.push_back({i, n});
+    *grouped |= n > 1;
+    i += n;
+  }
+  return nodes;
+}
+static int run_node(const std::vector<Launch>& L, const Node& nd, hipStream_t s) {
+  if (nd.n == 1) return run_launch(L[nd.first], s);
+  ConvMulti m;
+  Launch ml;
+  const int rc = describe_multi(&L[nd.first], nd.n, &m, &ml);
+  if (rc) return rc;
+  void* args[] = {&m};
+  UDP_HIP_CHECK(hipLaunchKernel(ml.fn, ml.grid, ml.block, args, ml.lds, s));
+  return UDP_OK;
+}
+
 // Eager execution.  lanes != 0: ops run on their lane's stream (lane 0 = s) with event edges for
 // the cross-lane dependencies the host planner listed, forked from / joined back into s.
 // ev != null: serial on s with an event pair around every op (profiling).
 static int enqueue_all(udp_hrnet* h, const std::vector<Launch>& L, hipStream_t s, hipEvent_t* ev, int lanes) {
+  bool grouped = false;
+  const std::vector<Node> nodes = make_nodes(h, L, &grouped);
+  if (grouped) {
+    // merged launches span lanes: one chain on s, the same launches the graph replays.  Profiling: the
+    // event pair of a merged launch sits on its first op; udp_hrnet_profile splits the time over the members
+    for (const Node& nd : nodes) {
+      if (ev) UDP_HIP_CHECK(hipEventRecord(ev[2 * nd.first], s));
+      const int rc = run_node(L, nd, s);
+      if (rc) return rc;
+      if (ev) UDP_HIP_CHECK(hipEventRecord(ev[2 * nd.first + 1], s));
+    }
+    return UDP_OK;
+  }
   lanes = lanes && h->n_lanes > 1 && !ev && getenv("UDP_POSE_SERIAL") == nullptr;
   hipStream_t ls[UDP_MAX_LANES] = {s, s, s, s};
   if (lanes) {
@@ -335,18 +377,8 @@ static int enqueue_all(udp_hrnet* h, const std::vector<Launch>& L, hipStream_t s
 // the planner's cross-lane dependencies, so independent HRNet branches overlap on the GPU.
 static int build_graph(udp_hrnet* h, const std::vector<Launch>& L, hipGraph_t* graph, hipGraphExec_t* exec) {
   UDP_HIP_CHECK(hipGraphCreate(graph, 0));
-  // launch list: runs of groupable convs with the same group id become one conv_mfma_multi launch
-  struct Node { size_t first; int n; };
-  std::vector<Node> nodes;
   bool grouped = false;
-  for (size_t i = 0; i < L.size();) {
-    int n = 1;
-    if (L[i].groupable && h->ops[i].group != 0)
-      while (n < 4 && i + n < L.size() && L[i + n].groupable / 10 == L[i].groupable / 10 && h->ops[i + n].group == h->ops[i].group) ++n;
-    nodes.push_back({i, n});
-    grouped |= n > 1;
-    i += n;
-  }
+  const std::vector<Node> nodes = make_nodes(h, L, &grouped);
   std::vector<hipGraphNode_t> node(nodes.size());
   std::vector<int> node_of_op(L.size(), -1);
   int last_on_lane[UDP_MAX_LANES] = {-1, -1, -1, -1};
@@ -422,9 +454,18 @@ extern "C" int udp_hrnet_profile(udp_hrnet* h, const float* in_nchw, int n, int 
   for (auto& e : ev) UDP_HIP_CHECK(hipEventCreate(&e));
   rc = enqueue_all(h, L, s, ev.data(), 0);
   hipError_t se = hipStreamSynchronize(s);
-  if (!rc && se == hipSuccess)
-    for (size_t i = 0; i < nops; ++i)
-      if (hipEventElapsedTime(&ms_per_op[i], ev[2 * i], ev[2 * i + 1]) != hipSuccess) ms_per_op[i] = -1.f;
+  if (!rc && se == hipSuccess) {
+    bool grouped = false;
+    for (const Node& nd : make_nodes(h, L, &grouped)) {
+      float t = -1.f;
+      if (hipEventElapsedTime(&t, ev[2 * nd.first], ev[2 * nd.first + 1]) != hipSuccess) t = -1.f;
+      // a merged launch: its time is shared by the members in proportion to their FLOPs
+      double total = 0.0;
+      auto flops = [&](size_t i) { const udp_conv_op& o = h->ops[i]; return (double)o.ks * o.ks * o.cin * o.cout * o.hout * o.wout; };
+      for (int j = 0; j < nd.n; ++j) total += flops(nd.first + j);
+      for (int j = 0; j < nd.n; ++j) ms_per_op[nd.first + j] = nd.n == 1 || t < 0 ? t : (float)(t * flops(nd.first + j) / total);
+    }
+  }
   for (auto& e : ev) (void)hipEventDestroy(e);
   if (rc) return rc;
   if (se != hipSuccess) return fail(UDP_ERR_HIP, "hipStreamSynchronize: %s", hipGetErrorString(se));
