@@ -37,8 +37,26 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int ROWB = 64;   // LDS row: one pixel's (or one weight row's) 64-byte channel chunk
 constexpr int MAXG = 10;   // 16-row staging groups per wave for the input tile (<= 640 rows)
 
-// 16-byte part p of LDS row r is stored at part position p ^ swz(r)
-__device__ __forceinline__ int swz(int row) { return (-(row >> 2)) & 3; }
+// 16-byte part p of LDS row r is stored at part position p ^ swz<T>(r).  The swizzle makes the MFMA operand
+// reads of 16 CONSECUTIVE rows (any start row: the taps shift the window) bank-conflict free:
+//   fp32 (ds_read_b64, lane groups = the 32-lane halves: one part of 16 rows): the 4 rows with equal row&3
+//        need 4 different positions -> a permutation of (row>>2)&3;
+//   bf16 (ds_read_b128, lane groups {0-3,12-15,20-27},...: rows 0-3 and 12-15 with part a, rows 4-11 with
+//        part a^1): positions {f(q), f(q+1)^1, f(q+2)^1, f(q+3)} must differ for EVERY q -> f = (0,2,0,2).
+//        (The permutation (0,3,2,1) is conflict free only for windows starting at a multiple of 4 rows; PMC
+//        SQ_LDS_BANK_CONFLICT showed ~16 % of the conv kernels' cycles with it.)
+template <typename T>
+__device__ __forceinline__ int swz(int row) {
+#ifdef UDP_OLD_SWZ   // A/B build only
+  return (-(row >> 2)) & 3;
+#else
+  if constexpr (std::is_same<T, float>::value) {
+    return (-(row >> 2)) & 3;
+  } else {
+    return (row >> 1) & 2;
+  }
+#endif
+}
 
 #ifdef UDP_STAMPS
 // Diagnostic build (libudp_pose_hip_stamps.so, tools/stamp_conv.py): s_memtime stamps per wave into a
@@ -235,7 +253,7 @@ __device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[MBW][NB], const unsigned
 #pragma unroll
     for (int i = 0; i < MBW; ++i) {
       const int row = prow[i] + tap_rows;
-      x[i] = *reinterpret_cast<const Frag*>(sb + row * ROWB + ((part ^ swz(row)) << 4) + sub);
+      x[i] = *reinterpret_cast<const Frag*>(sb + row * ROWB + ((part ^ swz<T>(row)) << 4) + sub);
     }
   };
   load(0, wf[0], pf[0]);
@@ -322,7 +340,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int ti
       const int n = n0 + g, gy = gy0 + iy, gx = gx0 + ix;
       const bool ok = row < npix_in && n < p.N && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win;
       const unsigned pix = __umul24(__umul24(n, p.Hin) + gy, p.Win) + gx;
-      off = ok ? pix * inpb + p.in_coff * ESZ + ((spart ^ swz(row)) << 4) : kOobOff;
+      off = ok ? pix * inpb + p.in_coff * ESZ + ((spart ^ swz<T>(row)) << 4) : kOobOff;
     }
     src_off[i] = off;
   }
@@ -336,7 +354,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int ti
       const int gidx = wave + NW * i;
       if (gidx < in_groups) {
         unsigned off = src_off[i] + coff;
-        if (cut && (spart ^ swz(gidx * 16 + srow)) >= parts_left) off = kOobOff;
+        if (cut && (spart ^ swz<T>(gidx * 16 + srow)) >= parts_left) off = kOobOff;
         blds16(r_in, off, sb + gidx * (16 * ROWB));
       }
     }
@@ -345,7 +363,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int ti
       const int tap = wr / BN;   // BN is a power of two
       const int rho = wr & (BN - 1);
       const int co = (4 * NB) * ((rho & 15) >> 2) + 4 * (rho >> 4) + (rho & 3);
-      const int lp = spart ^ swz(wr);
+      const int lp = spart ^ swz<T>(wr);
       unsigned e = __umul24(__umul24(tap, p.CoutPad) + cb * BN + co, cinb) + coff + (lp << 4);
       if (cut && lp >= parts_left) e = kOobOff;
       blds16(r_w, e, sb + in_bytes + gidx * (16 * ROWB));
@@ -372,7 +390,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int ti
     opix[i] = ok ? (int)pix : -1;
     ocrd[i] = ok ? (y | (xo << 10) | (n << 20)) : -1;
   }
-  const int wswz = swz(li);  // weight rows: (tap*BN + nb*16) is a multiple of 16 -> swizzle depends on li only
+  const int wswz = swz<T>(li);  // weight rows: (tap*BN + nb*16) is a multiple of 16 -> swizzle depends on li only
 
   f32x4 acc[MBW][NB];
   {
@@ -542,7 +560,7 @@ __global__ __launch_bounds__(256) void conv_mfma_persist1(const ConvParams p) {
       const int ix = row - (int)__umul24(tmp, IW);
       const int g = fdiv20(tmp, p.mIH);
       const int iy = tmp - (int)__umul24(g, IH);
-      s_rel[i] = (int)((__umul24(__umul24(g, p.Hin) + iy, p.Win) + ix) * cinb) + ((spart ^ swz(row)) << 4);
+      s_rel[i] = (int)((__umul24(__umul24(g, p.Hin) + iy, p.Win) + ix) * cinb) + ((spart ^ swz<T>(row)) << 4);
       s_crd[i] = row < npix_in ? (iy | (ix << 10) | (g << 20)) : -1;
     }
   }
@@ -562,7 +580,7 @@ __global__ __launch_bounds__(256) void conv_mfma_persist1(const ConvParams p) {
     o_rel[i] = (int)(((__umul24(__umul24(g, p.Hout) + r, p.Wout) + x) * p.Cout + cbase) * ESZ);
     o_crd[i] = (m0 < M && cbase < p.Cout) ? (r | (x << 10) | (g << 20)) : -1;
   }
-  const int wswz = swz(li);
+  const int wswz = swz<T>(li);
   f32x4 bias[NB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) bias[nb] = *reinterpret_cast<const f32x4*>(p.bias + cbase + 4 * nb);
@@ -602,7 +620,7 @@ __global__ __launch_bounds__(256) void conv_mfma_persist1(const ConvParams p) {
     const int rho = wr & (BN - 1);
     const int co = (4 * NB) * ((rho & 15) >> 2) + 4 * (rho >> 4) + (rho & 3);
     const unsigned e = __umul24(__umul24(tap, p.CoutPad) + cb * BN + co, cinb);
-    blds16(r_w, e + ((spart ^ swz(wr)) << 4), w_lds + gidx * (16 * ROWB));
+    blds16(r_w, e + ((spart ^ swz<T>(wr)) << 4), w_lds + gidx * (16 * ROWB));
   }
   stage_in(t, in_lds);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -731,7 +749,7 @@ __global__ __launch_bounds__(NW * 64) void basic_block_c32_kernel(const ConvPara
       const int row = (wave + NW * i) * 16 + srow;
       const int iy = fdiv20(row, p.mIW);
       const int ix = row - (int)__umul24(iy, IW);
-      s_rel[i] = (int)((__umul24(iy, W) + ix) * cinb) + ((spart ^ swz(row)) << 4);
+      s_rel[i] = (int)((__umul24(iy, W) + ix) * cinb) + ((spart ^ swz<T>(row)) << 4);
       s_crd[i] = row < npix_in ? (iy | (ix << 10)) : -1;
     }
   }
@@ -757,7 +775,7 @@ __global__ __launch_bounds__(NW * 64) void basic_block_c32_kernel(const ConvPara
     o_rel[i] = (int)((__umul24(r, W) + x) * cinb) + 16 * kg;
     o_r[i] = m0 < M2 ? r : -1;
   }
-  const int wswz = swz(li);
+  const int wswz = swz<T>(li);
   const int cbase = 4 * NB * kg;     // the lane's 8 consecutive output channels
   f32x4 bias1[NB], bias2[NB];
 #pragma unroll
@@ -794,7 +812,7 @@ __global__ __launch_bounds__(NW * 64) void basic_block_c32_kernel(const ConvPara
     const int tap = wr / BN;
     const int rho = wr & (BN - 1);
     const int co = (4 * NB) * ((rho & 15) >> 2) + 4 * (rho >> 4) + (rho & 3);
-    const unsigned e = (unsigned)(tap * BN + co) * cinb + ((spart ^ swz(wr)) << 4);
+    const unsigned e = (unsigned)(tap * BN + co) * cinb + ((spart ^ swz<T>(wr)) << 4);
     blds16(r_w1, e, w1_lds + gidx * (16 * ROWB));
     blds16(r_w2, e, w2_lds + gidx * (16 * ROWB));
   }
@@ -829,7 +847,7 @@ __global__ __launch_bounds__(NW * 64) void basic_block_c32_kernel(const ConvPara
             o[q] = (__bf16)(inside && a > 0.f ? a : 0.f);
             o[4 + q] = (__bf16)(inside && b > 0.f ? b : 0.f);
           }
-          *reinterpret_cast<bf16x8*>(mid_lds + row * ROWB + ((kg ^ swz(row)) << 4)) = o;
+          *reinterpret_cast<bf16x8*>(mid_lds + row * ROWB + ((kg ^ swz<T>(row)) << 4)) = o;
         }
       }
     }
@@ -847,7 +865,7 @@ __global__ __launch_bounds__(NW * 64) void basic_block_c32_kernel(const ConvPara
         const int r = o_r[i];
         const bool ok = r >= 0 && y0 + r < H;
         const int rrow = prow2[i] + 2 * IW + 1;                 // the block input at the output pixel
-        const bf16x8 x = *reinterpret_cast<const bf16x8*>(sb + rrow * ROWB + ((kg ^ swz(rrow)) << 4));
+        const bf16x8 x = *reinterpret_cast<const bf16x8*>(sb + rrow * ROWB + ((kg ^ swz<T>(rrow)) << 4));
         bf16x8 o;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
