@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """One eager HRNet-W32 forward (2N = 128 images) for counter collection under rocprofv3 --pmc."""
 import os, sys
+if "--per-op" in sys.argv:          # one launch per op (no merged launches): what tools/pmc_by_op.py maps onto the program
+    sys.argv.remove("--per-op")
+    os.environ["UDP_POSE_NO_GROUPS"] = "1"
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench

@@ -2,7 +2,9 @@
 """Map rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE dispatch rows of tools/one_forward.py onto the ops of
 the HRNet program (dispatch order == op order) and print HBM traffic per kernel class.
 
-    python tools/pmc_by_op.py <fetch_dir> <write_dir> [bf16|f32] > profiles/rNN_traffic.json
+    rocprofv3 --pmc FETCH_SIZE -d <fetch_dir> --output-format csv -- python3 tools/one_forward.py bf16 --per-op
+    rocprofv3 --pmc WRITE_SIZE -d <write_dir> --output-format csv -- python3 tools/one_forward.py bf16 --per-op
+    UDP_POSE_NO_GROUPS=1 python tools/pmc_by_op.py <fetch_dir> <write_dir> [bf16|f32] > profiles/rNN_traffic.json
 
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of a wide
 coalesced read (MI355X_MICROARCH.md, HBM section), so it is doubled here.
