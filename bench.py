@@ -201,7 +201,10 @@ def parity(net_dtype, sd, x, c, s, ref, ref_hm, device):
         preds, maxvals, _, _ = hp.step()
         torch.cuda.synchronize()
         err = np.abs(preds.cpu().numpy() - ref[0]).max(axis=2)
-        out[dt] = {"heatmap_max_abs_err": float(np.abs(hp.fused.cpu().numpy() - ref_hm).max()),
+        hm = hp.fused.cpu().numpy()
+        n, j = hm.shape[:2]
+        same = hm.reshape(n, j, -1).argmax(2) == ref_hm.reshape(n, j, -1).argmax(2)
+        out[dt] = {"heatmap_max_abs_err": float(np.abs(hm - ref_hm).max()), "argmax_equal_rate": float(same.mean()),
                    "keypoint_err_px_median": float(np.median(err)), "keypoint_err_px_p90": float(np.percentile(err, 90))}
     return out
 
