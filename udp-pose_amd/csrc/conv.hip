@@ -1134,6 +1134,11 @@ size_t conv_choose_tile(ConvParams& p, int ks, int stride, int dtype, int* nb_ou
   while (wgs(G, R, NB) < kMinWgs && G > 1) G = (G + 1) / 2;
   const size_t kLimit = (size_t)knob("UDP_POSE_LDS_KB", 76) * 1024;   // 76 KB: two workgroups per CU
   while ((lds(G, R, NB) > kLimit || npix(G, R) > MAXG * 64) && G > 1) --G;
+  // stride 2: the halo tile is 4x the output pixels -- rather keep 4 cout blocks per staged tile and
+  // shrink the tile (+0.4 % images/s; UDP_POSE_NO_S2_NB4 restores the old order)
+  static const bool s2nb4 = getenv("UDP_POSE_NO_S2_NB4") == nullptr;
+  if (s2nb4 && stride == 2 && NB == 4)
+    while ((lds(G, R, NB) > kLimit || npix(G, R) > MAXG * 64) && R > 2) R = (R + 1) / 2;
   while ((lds(G, R, NB) > kLimit || npix(G, R) > MAXG * 64) && NB == 4) NB = 2;
   while ((lds(G, R, NB) > kLimit || npix(G, R) > MAXG * 64) && R > 1) R = (R + 1) / 2;
   p.G = G;
