@@ -286,3 +286,22 @@ def test_mse_loss_matches_reference(golden_dir, is_offset):
         np.testing.assert_allclose(l[0], g["mse_loss"], rtol=1e-6)
         assert l[1] == 0
     np.testing.assert_allclose(grad.cpu().numpy(), g[pre + "grad"], rtol=1e-5, atol=1e-9)
+
+
+def test_dark_decode_recovers_subpixel_mean_on_device():
+    """KAT: noiseless Gaussians at sub-pixel means decode (POST_PROCESS on) to those
+    means.  preds_in_input_space = coord/(W-1)*(4W-1) (inference.py:177-179) is inverted to heat-map pixels."""
+    ys = np.arange(64, dtype=np.float64)[:, None]
+    xs = np.arange(48, dtype=np.float64)[None, :]
+    mus = [(20.3, 30.7), (10.5, 12.25), (40.1, 50.9), (1.2, 1.4), (46.6, 62.3)]
+    hm = np.stack([np.exp(-((xs - mx) ** 2 + (ys - my) ** 2) / 8.0) for mx, my in mus])[None].astype(np.float32)
+    c = torch.tensor([[96.0, 128.0]], dtype=torch.float64, device="cuda")
+    s = torch.tensor([[192.0 / 200, 256.0 / 200]], dtype=torch.float64, device="cuda")
+    preds, maxvals, pin, idx = uinf.decode_device(torch.from_numpy(hm).cuda(), c, s, "gaussian", True, 4.0, False)
+    got = pin.cpu().numpy()[0] / np.array([4 * 48 - 1, 4 * 64 - 1]) * np.array([47, 63])
+    np.testing.assert_allclose(got[:3], np.asarray(mus[:3]), atol=0.05)     # interior peaks; the two border peaks are
+    # biased by the reference's own border handling (reflect-101 blur, replicate-padded log map)
+    # and the same through the oracle, borders included: identical within 1e-3 px
+    rp, _, rpin, _ = odec.get_final_preds("gaussian", True, 4.0, hm.copy(), c.cpu().numpy(), s.cpu().numpy())
+    np.testing.assert_allclose(pin.cpu().numpy(), rpin, atol=1e-3)
+    np.testing.assert_allclose(preds.cpu().numpy(), rp, atol=1e-3)
