@@ -359,3 +359,23 @@ def test_merged_branch_launches_equal_separate_launches(monkeypatch):
     torch.testing.assert_close(outs["grouped"], outs["plain"], rtol=0, atol=0)
     torch.testing.assert_close(outs["grouped2"], outs["plain"], rtol=0, atol=0)
     torch.testing.assert_close(outs["eager"], outs["plain"], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_each_image_is_independent_of_its_batch(dtype):
+    """Size-independent property: an image's heat-maps do not depend on which batch it is in (ragged tiles,
+    several-images-per-tile kernels, merged launches, fused blocks, flip-test row order): batch of 5 vs the
+    same images alone and in a batch of 2 -- bit-identical."""
+    extra = synth.scaled_extra(32, modules=(1, 1, 2), blocks=2)
+    sd = synth.synth_state_dict(extra, 17, "gaussian", seed=21)
+    x = torch.from_numpy(synth.synth_crops(5, 128, 96, seed=22))
+    ohrnet.hrnet_forward(sd, extra, x, calibrate=True)
+    net = MODELS["pose_hrnet"](_cfg(extra, 17, "gaussian"), is_train=False, dtype=dtype).load_state_dict(sd).to("cuda")
+    xd = x.cuda()
+    whole = net.raw_forward(xd, flip_test=True).clone()
+    for i in range(5):
+        one = net.raw_forward(xd[i:i + 1].contiguous(), flip_test=True).clone()
+        torch.testing.assert_close(one[0], whole[i], rtol=0, atol=0)
+        torch.testing.assert_close(one[1], whole[5 + i], rtol=0, atol=0)
+    two = net.raw_forward(xd[3:5].contiguous(), flip_test=False).clone()
+    torch.testing.assert_close(two, whole[3:5], rtol=0, atol=0)
