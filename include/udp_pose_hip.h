@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UDP_POSE_ABI_VERSION 10
+#define UDP_POSE_ABI_VERSION 11
 
 enum udp_status {
   UDP_OK = 0,
@@ -228,11 +228,14 @@ int udp_mse_loss(const float* pred, const float* target, const float* weight, in
  * use_vis != 0 reproduces oks_iou's in_vis_thre branch (only joints of the candidate above
  * oks_vis_thre count).  scores_out fp64 [P]; keep_rank int32 [P]: position in the keep list (selection
  * order = descending score) or -1 when suppressed (overlap > oks_thre with a kept pose).
+ * soft != 0: soft_oks_nms (nms.py:139-175, TEST.SOFT_NMS): instead of suppressing, the remaining scores
+ * are multiplied by exp(-oks^2 / oks_thre) after every pick; at most 20 picks per image.  scores_out still
+ * holds the (re)scores before NMS, as the reference never writes the decayed scores back.
  * ------------------------------------------------------------------------- */
 int udp_oks_nms(const float* kpts, const double* areas, const double* box_scores,
                 const int32_t* img_offsets, const int32_t* img_offsets_host, int n_images, int num_joints,
                 const double* vars_dev, double in_vis_thre, int rescore, double oks_thre, int use_vis,
-                double oks_vis_thre, double* scores_out, int32_t* keep_rank, void* stream);
+                double oks_vis_thre, int soft, double* scores_out, int32_t* keep_rank, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Training step (deep_hrnet/lib/core/function.py:38-77: model.train(), forward,

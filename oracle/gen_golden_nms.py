@@ -47,6 +47,8 @@ def main():
             for thr_tag, thr, vis in (("t9", 0.9, None), ("t5", 0.5, None), ("t5v", 0.5, 0.2)):
                 keep = nms.oks_nms(db, thr, None, vis)
                 out["c%d_keep_%s_%d" % (case, thr_tag, i)] = np.array(keep, np.int64)
+            for thr_tag, thr in (("t9", 0.9), ("t5", 0.5)):
+                out["c%d_soft_%s_%d" % (case, thr_tag, i)] = np.array(nms.soft_oks_nms(db, thr), np.int64)
             flat = kpts[a:b].reshape(b - a, -1)
             ious0.append(nms.oks_iou(flat[0], flat, areas[a], areas[a:b]))
         out["c%d_iou0" % case] = np.concatenate(ious0)

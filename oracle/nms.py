@@ -54,3 +54,22 @@ def rescore(keypoints, box_score, in_vis_thre):
     if valid != 0:
         kpt_score = kpt_score / valid
     return kpt_score * box_score
+
+
+def soft_oks_nms(kpts, scores, areas, thresh, sigmas=None, in_vis_thre=None):
+    """nms.py:139-175 (rescore() 'gaussian' :127-136): keep indices in selection order, at most 20."""
+    if len(scores) == 0:
+        return []
+    scores = np.asarray(scores, dtype=np.float64)
+    order = scores.argsort()[::-1]
+    scores = scores[order]
+    keep = []
+    while order.size > 0 and len(keep) < 20:
+        i = order[0]
+        ovr = oks_iou(kpts[i], kpts[order[1:]], areas[i], areas[order[1:]], sigmas, in_vis_thre)
+        order = order[1:]
+        scores = scores[1:] * np.exp(-ovr ** 2 / thresh)
+        tmp = scores.argsort()[::-1]
+        order, scores = order[tmp], scores[tmp]
+        keep.append(int(i))
+    return keep

@@ -21,6 +21,8 @@ def test_oracle_oks_nms_matches_reference(golden_dir):
             flat = kpts[a:b].reshape(b - a, -1)
             for tag, thr, vis in THR:
                 assert o_nms.oks_nms(flat, scores[a:b], areas[a:b], thr, None, vis) == list(g["c%d_keep_%s_%d" % (case, tag, i)])
+            for tag, thr in (("t9", 0.9), ("t5", 0.5)):
+                assert o_nms.soft_oks_nms(flat, scores[a:b], areas[a:b], thr) == list(g["c%d_soft_%s_%d" % (case, tag, i)])
             iou0.append(o_nms.oks_iou(flat[0], flat, areas[a], areas[a:b]))
         np.testing.assert_allclose(np.concatenate(iou0), g["c%d_iou0" % case], rtol=0, atol=1e-15)
     assert o_nms.oks_nms(np.zeros((0, 51)), np.zeros(0), np.zeros(0), 0.9) == []
@@ -37,6 +39,8 @@ def test_hip_oks_nms_matches_reference(golden_dir):
             db = [{"keypoints": kpts[p], "area": areas[p], "score": scores[p]} for p in range(a, b)]
             for tag, thr, vis in THR:
                 assert u_nms.oks_nms(db, thr, None, vis) == list(g["c%d_keep_%s_%d" % (case, tag, i)]), (case, i, tag)
+            for tag, thr in (("t9", 0.9), ("t5", 0.5)):
+                assert u_nms.soft_oks_nms(db, thr) == list(g["c%d_soft_%s_%d" % (case, tag, i)]), (case, i, tag)
     assert u_nms.oks_nms([], 0.9) == []
 
 

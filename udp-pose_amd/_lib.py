@@ -15,7 +15,7 @@ UDP_F32, UDP_BF16 = 0, 1
 UDP_OP_STEM, UDP_OP_CONV, UDP_OP_FUSE, UDP_OP_STEM7, UDP_OP_MAXPOOL, UDP_OP_BILINEAR = 0, 1, 2, 3, 4, 5
 UDP_OP_PSA_POOL, UDP_OP_PSA_MLP, UDP_OP_PSA_SCALE, UDP_OP_PSA_SP, UDP_OP_BLOCK = 6, 7, 8, 9, 10
 UDP_BUF_NONE, UDP_BUF_OUTPUT = -1, -2
-ABI_VERSION = 10
+ABI_VERSION = 11
 MAX_LANES, MAX_WAIT = 4, 8
 
 
@@ -80,7 +80,7 @@ _SIGS = {
                                     C.c_float, _P, _P, _P]),
     "udp_mse_loss": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "udp_oks_nms": (C.c_int, [_P, _P, _P, _P, C.POINTER(C.c_int32), C.c_int, C.c_int, _P, C.c_double, C.c_int,
-                              C.c_double, C.c_int, C.c_double, _P, _P, _P]),
+                              C.c_double, C.c_int, C.c_double, C.c_int, _P, _P, _P]),
     # training step
     "udp_pack_conv_weights": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "udp_pack_conv_weights_batch": (C.c_int, [_P, C.c_int, C.c_int, _P]),

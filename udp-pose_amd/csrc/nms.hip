@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void oks_nms_kernel(const float* __restrict__ 
                                                       const double* __restrict__ box_scores,
                                                       const int32_t* __restrict__ offs, int J,
                                                       const double* __restrict__ vars, double in_vis_thre, int rescore,
-                                                      double oks_thre, int use_vis, double oks_vis_thre,
+                                                      double oks_thre, int use_vis, double oks_vis_thre, int soft,
                                                       double* __restrict__ scores_out, int32_t* __restrict__ keep_rank) {
   __shared__ double sc[kMaxPersons];
   __shared__ int order[kMaxPersons];
@@ -58,6 +58,58 @@ __global__ __launch_bounds__(256) void oks_nms_kernel(const float* __restrict__ 
     order[r] = p;
   }
   __syncthreads();
+  if (soft) {
+    // soft_oks_nms (nms.py:139-175): pick the best remaining pose, multiply every other remaining score by
+    // exp(-oks^2 / thresh) (rescore(), 'gaussian'), repeat; at most 20 detections per image
+    __shared__ double red_v[256];
+    __shared__ int red_i[256];
+    for (int k = 0; k < P && k < 20; ++k) {
+      double bv = -1.0;
+      int bi = -1;
+      for (int q = t; q < P; q += 256)
+        if (!dead[q] && (sc[q] > bv || (sc[q] == bv && q > bi))) {
+          bv = sc[q];
+          bi = q;
+        }
+      red_v[t] = bv;
+      red_i[t] = bi;
+      __syncthreads();
+      for (int o = 128; o > 0; o >>= 1) {
+        if (t < o && (red_v[t + o] > red_v[t] || (red_v[t + o] == red_v[t] && red_i[t + o] > red_i[t]))) {
+          red_v[t] = red_v[t + o];
+          red_i[t] = red_i[t + o];
+        }
+        __syncthreads();
+      }
+      const int i = red_i[0];
+      if (i < 0) break;                                  // uniform
+      if (t == 0) {
+        keep_rank[a + i] = k;
+        dead[i] = 1;
+      }
+      for (int e = t; e < J * 3; e += 256) gk[e] = kpts[(long)(a + i) * J * 3 + e];
+      __syncthreads();
+      const double ag = areas[a + i];
+      for (int d = t; d < P; d += 256) {
+        if (dead[d]) continue;
+        const float* kp = kpts + (long)(a + d) * J * 3;
+        const double den = (ag + areas[a + d]) / 2 + 2.220446049250313e-16;
+        double sum = 0.0;
+        int cnt = 0;
+        for (int j = 0; j < J; ++j) {
+          if (use_vis && !((double)kp[3 * j + 2] > oks_vis_thre)) continue;
+          const float dx = kp[3 * j] - gk[3 * j], dy = kp[3 * j + 1] - gk[3 * j + 1];
+          const float d2 = dx * dx + dy * dy;
+          sum += exp(-((double)d2 / svar[j] / den / 2));
+          ++cnt;
+        }
+        const double iou = cnt ? sum / (double)cnt : 0.0;
+        sc[d] = sc[d] * exp(-(iou * iou) / oks_thre);
+      }
+      __syncthreads();
+    }
+    return;
+  }
   int kept = 0;
   for (int r = 0; r < P; ++r) {
     const int i = order[r];
@@ -95,7 +147,7 @@ using namespace udp;
 
 extern "C" int udp_oks_nms(const float* kpts, const double* areas, const double* box_scores, const int32_t* img_offsets,
                            const int32_t* img_offsets_host, int n_images, int num_joints, const double* vars_dev,
-                           double in_vis_thre, int rescore, double oks_thre, int use_vis, double oks_vis_thre,
+                           double in_vis_thre, int rescore, double oks_thre, int use_vis, double oks_vis_thre, int soft,
                            double* scores_out, int32_t* keep_rank, void* stream) {
   if (!kpts || !areas || !box_scores || !img_offsets || !img_offsets_host || !vars_dev || !scores_out || !keep_rank)
     return fail(UDP_ERR_ARG, "udp_oks_nms: null pointer");
@@ -108,7 +160,7 @@ extern "C" int udp_oks_nms(const float* kpts, const double* areas, const double*
   if (n_images == 0) return UDP_OK;
   hipLaunchKernelGGL(oks_nms_kernel, dim3(n_images), dim3(256), 0, (hipStream_t)stream, kpts, areas, box_scores,
                      img_offsets, num_joints, vars_dev, in_vis_thre, rescore ? 1 : 0, oks_thre, use_vis ? 1 : 0,
-                     oks_vis_thre, scores_out, keep_rank);
+                     oks_vis_thre, soft ? 1 : 0, scores_out, keep_rank);
   UDP_HIP_CHECK(hipGetLastError());
   return UDP_OK;
 }

@@ -2,7 +2,7 @@
 
 Mirrors deep_hrnet/lib/nms/nms.py:99-124 (``oks_nms(kpts_db, thresh, sigmas=None, in_vis_thre=None)`` ->
 keep indices) and the per-image loop of deep_hrnet/lib/dataset/coco.py:321-356 (``rescore_and_nms``: all
-images of an evaluation in ONE launch).  ``soft_oks_nms`` (TEST.SOFT_NMS, default False) is not built.
+images of an evaluation in ONE launch) and ``soft_oks_nms`` (:139-175, TEST.SOFT_NMS).
 """
 import ctypes as C
 
@@ -14,7 +14,7 @@ from . import _lib
 COCO_SIGMAS = np.array([.26, .25, .25, .35, .35, .79, .79, .72, .72, .62, .62, 1.07, 1.07, .87, .87, .89, .89]) / 10.0
 
 
-def _run(kpts, areas, box_scores, offsets, in_vis_thre, rescore, oks_thre, sigmas, oks_vis_thre, device):
+def _run(kpts, areas, box_scores, offsets, in_vis_thre, rescore, oks_thre, sigmas, oks_vis_thre, device, soft=False):
     kpts = np.ascontiguousarray(kpts, dtype=np.float32)
     p, j = kpts.shape[0], kpts.shape[1]
     sig = COCO_SIGMAS if not isinstance(sigmas, np.ndarray) else sigmas
@@ -32,7 +32,7 @@ def _run(kpts, areas, box_scores, offsets, in_vis_thre, rescore, oks_thre, sigma
     _lib.check(_lib.lib().udp_oks_nms(k_d.data_ptr(), a_d.data_ptr(), b_d.data_ptr(), o_d.data_ptr(),
                                       offsets.ctypes.data_as(C.POINTER(C.c_int32)), len(offsets) - 1, j, v_d.data_ptr(),
                                       float(in_vis_thre), int(rescore), float(oks_thre),
-                                      int(oks_vis_thre is not None), float(oks_vis_thre or 0.0), scores.data_ptr(),
+                                      int(oks_vis_thre is not None), float(oks_vis_thre or 0.0), int(soft), scores.data_ptr(),
                                       rank.data_ptr(), _lib.stream_ptr()))
     return scores.cpu().numpy(), rank.cpu().numpy()
 
@@ -49,7 +49,19 @@ def oks_nms(kpts_db, thresh, sigmas=None, in_vis_thre=None, device="cuda"):
     return [int(i) for i in keep[np.argsort(rank[keep])]]
 
 
-def rescore_and_nms(preds, all_boxes, image_ids, in_vis_thre, oks_thre, device="cuda"):
+def soft_oks_nms(kpts_db, thresh, sigmas=None, in_vis_thre=None, device="cuda"):
+    """nms.py:139-175: Gaussian score decay instead of suppression, at most 20 detections."""
+    if len(kpts_db) == 0:
+        return []
+    kpts = np.stack([np.asarray(d["keypoints"], dtype=np.float32).reshape(-1, 3) for d in kpts_db])
+    scores = np.array([d["score"] for d in kpts_db], dtype=np.float64)
+    areas = np.array([d["area"] for d in kpts_db], dtype=np.float64)
+    _, rank = _run(kpts, areas, scores, [0, len(kpts_db)], 0.0, False, thresh, sigmas, in_vis_thre, device, soft=True)
+    keep = np.where(rank >= 0)[0]
+    return [int(i) for i in keep[np.argsort(rank[keep])]]
+
+
+def rescore_and_nms(preds, all_boxes, image_ids, in_vis_thre, oks_thre, device="cuda", soft_nms=False):
     """coco.py:306-356 for a whole evaluation: preds [P,J,3] (x, y, score), all_boxes [P,6] (center 0:2,
     scale 2:4, area 4, score 5), image_ids [P].  Returns per image id the kept persons
     {'keypoints', 'center', 'scale', 'area', 'score' (rescored), 'image'} in keep order."""
@@ -63,7 +75,7 @@ def rescore_and_nms(preds, all_boxes, image_ids, in_vis_thre, oks_thre, device="
     perm = np.array([i for im in first for i in first[im]], dtype=np.int64)
     offsets = np.cumsum([0] + [len(first[im]) for im in first]).astype(np.int32)
     scores, rank = _run(preds[perm], all_boxes[perm, 4], all_boxes[perm, 5], offsets, in_vis_thre, True, oks_thre, None,
-                        None, device)
+                        None, device, soft=soft_nms)
     out = {}
     for n, im in enumerate(first):
         a, b = offsets[n], offsets[n + 1]
