@@ -1,0 +1,83 @@
+"""``train`` / ``validate`` / criteria with the reference's call shapes (udp-pose_amd/function.py) against the
+CPU oracle: validate() fills all_preds / all_boxes as function.py:212-221 does from forward + flip test +
+get_final_preds; the criteria equal oracle/loss.py; train() drives HRNetTrainer over a loader."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import decode as odec, flip as oflip, hrnet as ohrnet, loss as oloss   # noqa: E402
+from udp_pose_amd import function as ufn, synth                                      # noqa: E402
+from udp_pose_amd.model import MODELS                                                 # noqa: E402
+from udp_pose_amd.train import HRNetTrainer                                           # noqa: E402
+from udp_pose_amd.transforms import COCO_FLIP_PAIRS                                   # noqa: E402
+
+EXTRA = synth.scaled_extra(32, modules=(1, 1, 1), blocks=1)
+
+
+class _DS:
+    flip_pairs = COCO_FLIP_PAIRS
+
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+
+def _loader(n_batches, bs, tt, seed):
+    out = []
+    for b in range(n_batches):
+        x = torch.from_numpy(synth.synth_crops(bs, 128, 96, seed=seed + b))
+        k = 3 if tt == "offset" else 1
+        tg = torch.from_numpy(synth.synth_heatmaps(bs, 17, 32, 24, seed=seed + 50 + b, channels_per_joint=k))
+        tw = torch.from_numpy((np.random.default_rng(seed + b).random((bs, 17, 1)) > 0.2).astype(np.float32))
+        c, s = synth.synth_center_scale(bs, seed=seed + b)
+        out.append((x, tg, tw, {"center": c, "scale": s, "score": np.full(bs, 0.5 + 0.1 * b),
+                                "image": ["img_%d_%d" % (b, i) for i in range(bs)]}))
+    return out
+
+
+@pytest.mark.parametrize("tt,post", [("gaussian", True), ("gaussian", False), ("offset", False)])
+def test_validate_matches_oracle_pipeline(tt, post):
+    cfg = {"MODEL": {"EXTRA": EXTRA, "NUM_JOINTS": 17, "TARGET_TYPE": tt}, "TEST": {"FLIP_TEST": True, "POST_PROCESS": post},
+           "LOSS": {"KPD": 4.0}}
+    sd = synth.synth_state_dict(EXTRA, 17, tt, seed=31)
+    loader = _loader(2, 3, tt, 60)
+    ohrnet.hrnet_forward(sd, EXTRA, loader[0][0], calibrate=True)
+    net = MODELS["pose_hrnet"](cfg, is_train=False).load_state_dict(sd).to("cuda")
+    crit = ufn.JointsMSELoss_offset() if tt == "offset" else ufn.JointsMSELoss()
+    all_preds, all_boxes, paths, mean_loss = ufn.validate(cfg, loader, _DS(6), net, crit)
+    ref_p, ref_l, idx = [], 0.0, 0
+    for x, tg, tw, meta in loader:
+        y = ohrnet.hrnet_forward(sd, EXTRA, torch.cat([x, torch.flip(x, dims=[3])])).numpy()
+        hm = oflip.flip_fuse(y[:3], y[3:], oflip.COCO_FLIP_PAIRS, tt == "offset")
+        if tt == "offset":
+            l_hm, l_os, _ = oloss.joints_mse_loss_offset(hm, tg.numpy(), tw.numpy())
+            ref_l += (l_hm + l_os) * 3
+        else:
+            ref_l += oloss.joints_mse_loss(hm, tg.numpy(), tw.numpy())[0] * 3
+        p, m, _, _ = odec.get_final_preds(tt, post, 4.0, hm.copy(), meta["center"], meta["scale"])
+        ref_p.append(np.concatenate([p, m], axis=2))
+        np.testing.assert_allclose(all_boxes[idx:idx + 3, 4], np.prod(meta["scale"] * 200, 1))
+        np.testing.assert_allclose(all_boxes[idx:idx + 3, 5], meta["score"])
+        idx += 3
+    ref_p = np.concatenate(ref_p)
+    assert paths == ["img_%d_%d" % (b, i) for b in range(2) for i in range(3)]
+    np.testing.assert_allclose(mean_loss, ref_l / 6, rtol=1e-4)
+    np.testing.assert_allclose(all_preds[..., 2], ref_p[..., 2], atol=1e-3)
+    err = np.abs(all_preds[..., :2] - ref_p[..., :2]).max(axis=2)
+    assert np.median(err) < 1e-2 and (err < 0.5).mean() > 0.9, (np.median(err), (err < 0.5).mean())
+
+
+def test_train_epoch_drives_the_trainer():
+    cfg = {"MODEL": {"EXTRA": EXTRA, "NUM_JOINTS": 17, "TARGET_TYPE": "gaussian"}}
+    sd = synth.synth_state_dict(EXTRA, 17, "gaussian", seed=32)
+    loader = _loader(1, 4, "gaussian", 70) * 6                  # the same batch six times: the loss must fall
+    tr = HRNetTrainer(cfg, sd, device="cuda", lr=1e-3)
+    first = ufn.train(cfg, loader[:1], tr, ufn.JointsMSELoss(), None, 0)
+    last = None
+    for _ in range(3):
+        last = ufn.train(cfg, loader, tr, ufn.JointsMSELoss(), None, 1)
+    assert last < 0.8 * first and tr.step_count == 1 + 18

@@ -1,0 +1,122 @@
+"""``train`` / ``validate`` with the reference's call shapes (deep_hrnet/lib/core/function.py:27-111,
+:114-255) and the criteria of lib/core/loss.py, all arithmetic in libudp_pose_hip.so.
+
+* ``JointsMSELoss`` / ``JointsMSELoss_offset`` (loss.py:15-39 / :41-76): callables returning the loss
+  value(s) as device fp64 scalars (``udp_mse_loss``); ``.last_grad`` holds d loss / d output.
+* ``train(config, train_loader, model, criterion, optimizer, epoch, ...)``: ``model`` is a
+  ``train.HRNetTrainer`` (it owns parameters, Adam state and the backward); ``criterion`` / ``optimizer`` are
+  accepted for signature compatibility (the trainer runs the same criterion and Adam rule internally).
+* ``validate(config, val_loader, val_dataset, model, criterion, ...)``: forward + mirrored forward in one
+  launch sequence, ``udp_flip_fuse``, loss, ``get_final_preds``; fills ``all_preds`` / ``all_boxes`` exactly as
+  :212-221 does and hands them to ``val_dataset.evaluate`` when the dataset has one.
+Logging / tensorboard / debug images of the reference are out of scope.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .inference import get_final_preds
+from .transforms import flip_fuse
+
+
+def _cfg(config, *path, default=None):
+    cur = config
+    for p in path:
+        try:
+            cur = cur[p] if isinstance(cur, dict) else getattr(cur, p)
+        except (KeyError, AttributeError):
+            return default
+    return cur
+
+
+class JointsMSELoss:
+    """loss.py:15-39.  ``use_target_weight=False`` weights every joint with 1."""
+    is_offset = False
+
+    def __init__(self, use_target_weight=True):
+        self.use_target_weight = use_target_weight
+        self.last_grad = None
+
+    def _run(self, output, target, target_weight):
+        if not output.is_cuda:
+            raise RuntimeError("udp-pose_amd has no CPU path: the criterion needs device tensors")
+        output, target = output.contiguous(), target.contiguous()
+        b, c = output.shape[:2]
+        j = c // 3 if self.is_offset else c
+        w = target_weight.reshape(b, j).to(torch.float32).contiguous() if self.use_target_weight else \
+            torch.ones(b, j, dtype=torch.float32, device=output.device)
+        loss = torch.zeros(2, dtype=torch.float64, device=output.device)
+        self.last_grad = torch.empty_like(output)
+        _lib.check(_lib.lib().udp_mse_loss(output.data_ptr(), target.data_ptr(), w.data_ptr(), b, j,
+                                           output.shape[2] * output.shape[3], int(self.is_offset), loss.data_ptr(),
+                                           self.last_grad.data_ptr(), _lib.stream_ptr()))
+        return loss
+
+    def __call__(self, output, target, target_weight):
+        return self._run(output, target, target_weight)[0]
+
+
+class JointsMSELoss_offset(JointsMSELoss):
+    """loss.py:41-76: returns (loss_hm, loss_os)."""
+    is_offset = True
+
+    def __call__(self, output, target, target_weight):
+        loss = self._run(output, target, target_weight)
+        return loss[0], loss[1]
+
+
+def train(config, train_loader, model, criterion=None, optimizer=None, epoch=0, output_dir=None, tb_log_dir=None,
+          writer_dict=None, world_size=1):
+    """function.py:27-111.  Returns the sample-weighted mean loss of the epoch (what ``losses.avg`` holds)."""
+    total, count = torch.zeros(2, dtype=torch.float64, device=model.device), 0
+    for input, target, target_weight, meta in train_loader:
+        n = input.shape[0]
+        loss = model.train_step(input.to(model.device, non_blocking=True).contiguous(),
+                                target.to(model.device, non_blocking=True), target_weight.to(model.device, non_blocking=True),
+                                world_size=world_size)
+        total += loss * n
+        count += n
+    return float(total.sum().item()) / max(count, 1)
+
+
+def validate(config, val_loader, val_dataset, model, criterion=None, output_dir=None, tb_log_dir=None, writer_dict=None):
+    """function.py:114-255.  Returns ``val_dataset.evaluate(...)``'s (name_values, perf_indicator) when the dataset
+    provides it, else (all_preds, all_boxes, image_path, mean_loss)."""
+    num_joints = int(_cfg(config, "MODEL", "NUM_JOINTS"))
+    tt = _cfg(config, "MODEL", "TARGET_TYPE", default="gaussian")
+    flip_test = bool(_cfg(config, "TEST", "FLIP_TEST", default=False))
+    flip_pairs = getattr(val_dataset, "flip_pairs", None)
+    num_samples = len(val_dataset)
+    all_preds = np.zeros((num_samples, num_joints, 3), dtype=np.float32)
+    all_boxes = np.zeros((num_samples, 6))
+    image_path, idx = [], 0
+    loss_sum, loss_n = 0.0, 0
+    for input, target, target_weight, meta in val_loader:
+        x = input.to(model.device if model.device is not None else "cuda").contiguous()
+        n = x.shape[0]
+        if flip_test:
+            raw = model.raw_forward(x, flip_test=True)
+            output = flip_fuse(raw[:n], raw[n:], flip_pairs, tt == "offset")
+        else:
+            output = model(x).clone()
+        if criterion is not None:
+            loss = criterion(output, target.to(output.device), target_weight.to(output.device))
+            loss = loss[0] + loss[1] if isinstance(loss, tuple) else loss
+            loss_sum += float(loss.item()) * n
+            loss_n += n
+        c = np.asarray(meta["center"])
+        s = np.asarray(meta["scale"])
+        score = np.asarray(meta["score"]) if "score" in meta else np.ones(n)
+        preds, maxvals, _ = get_final_preds(config, output, c, s)
+        all_preds[idx:idx + n, :, 0:2] = preds[:, :, 0:2]
+        all_preds[idx:idx + n, :, 2:3] = maxvals
+        all_boxes[idx:idx + n, 0:2] = c[:, 0:2]
+        all_boxes[idx:idx + n, 2:4] = s[:, 0:2]
+        all_boxes[idx:idx + n, 4] = np.prod(s * 200, 1)
+        all_boxes[idx:idx + n, 5] = score
+        image_path.extend(meta["image"] if "image" in meta else [""] * n)
+        idx += n
+    mean_loss = loss_sum / max(loss_n, 1)
+    if hasattr(val_dataset, "evaluate"):
+        return val_dataset.evaluate(config, all_preds, output_dir, all_boxes, image_path, [], [])
+    return all_preds, all_boxes, image_path, mean_loss
