@@ -81,3 +81,15 @@ def test_train_epoch_drives_the_trainer():
     for _ in range(3):
         last = ufn.train(cfg, loader, tr, ufn.JointsMSELoss(), None, 1)
     assert last < 0.8 * first and tr.step_count == 1 + 18
+
+
+def test_accuracy_matches_reference_fixture(golden_dir):
+    """evaluate.accuracy (PCK on heat-maps): device arg-max + host bookkeeping vs the reference's own function."""
+    import os
+    g = np.load(os.path.join(golden_dir, "accuracy.npz"))
+    for k, (seed, shift) in enumerate(((3, 0), (4, 3), (5, 6))):
+        pred, tgt = synth.synth_accuracy_case(seed, shift)
+        acc, avg, cnt, p = ufn.accuracy(torch.from_numpy(pred).cuda(), torch.from_numpy(tgt).cuda())
+        np.testing.assert_allclose(acc, g["acc%d" % k], rtol=0, atol=1e-12)
+        assert abs(avg - float(g["avg%d" % k])) < 1e-12 and cnt == int(g["cnt%d" % k])
+        np.testing.assert_array_equal(p, g["p%d" % k])

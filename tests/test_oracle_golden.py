@@ -220,3 +220,16 @@ def test_rsn18_matches_reference(golden_dir, och):
     x = torch.from_numpy(synth.synth_crops(1, 256, 192, seed=8))
     y = orsn.rsn_forward(sd, x).numpy()
     np.testing.assert_allclose(y, _g(golden_dir, "rsn18_%d.npz" % och)["out"], rtol=0, atol=1e-5)
+
+
+def test_accuracy_matches_reference(golden_dir):
+    """oracle/evaluate.accuracy == lib/core/evaluate.py:40-73 (fixture from the reference's function)."""
+    from oracle import evaluate as oev
+    g = _g(golden_dir, "accuracy.npz")
+    for k, (seed, shift) in enumerate(((3, 0), (4, 3), (5, 6))):
+        pred, tgt = synth.synth_accuracy_case(seed, shift)
+        acc, avg, cnt, p = oev.accuracy(pred, tgt)
+        np.testing.assert_allclose(acc, g["acc%d" % k], rtol=0, atol=1e-12)
+        assert abs(avg - float(g["avg%d" % k])) < 1e-12 and cnt == int(g["cnt%d" % k])
+        np.testing.assert_array_equal(p, g["p%d" % k])
+    assert 0.1 < float(g["avg1"]) < 0.9                       # a case that is neither all right nor all wrong

@@ -65,6 +65,45 @@ class JointsMSELoss_offset(JointsMSELoss):
         return loss[0], loss[1]
 
 
+def accuracy(output, target, hm_type="gaussian", thr=0.5):
+    """lib/core/evaluate.py:40-73: PCK on heat-maps (prediction arg-max vs ground-truth arg-max, distances in
+    units of a tenth of the map size, joints whose target arg-max is at x <= 1 or y <= 1 ignored).  The two
+    arg-max passes run on the device (udp_decode_gaussian); the [N,J] bookkeeping is host NumPy as there.
+    Returns (acc [J+1], avg_acc, cnt, pred [N,J,2])."""
+    from .inference import decode_device
+    if hm_type != "gaussian":
+        raise NotImplementedError("accuracy: hm_type %r (the reference only ever passes 'gaussian')" % hm_type)
+
+    def max_preds(hm):
+        hm = hm if isinstance(hm, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(hm, dtype=np.float32))
+        hm = hm.cuda() if not hm.is_cuda else hm
+        n, j, h, w = hm.shape
+        one = torch.ones(n, 2, dtype=torch.float64)
+        _, maxvals, _, idx = decode_device(hm, one, one, "gaussian", False, 4.0, True)
+        idx, mv = idx.cpu().numpy().astype(np.int64), maxvals.cpu().numpy()[..., 0]
+        p = np.stack([idx % w, idx // w], axis=2).astype(np.float32)
+        return p * (mv > 0.0)[..., None].astype(np.float32)                # get_max_preds: zero where max <= 0
+    n, j, h, w = output.shape
+    pred, tgt = max_preds(output), max_preds(target)
+    norm = np.ones((n, 2)) * np.array([h, w]) / 10
+    dists = np.full((j, n), -1.0)
+    ok = (tgt[..., 0] > 1) & (tgt[..., 1] > 1)
+    d = np.linalg.norm(pred / norm[:, None, :] - tgt / norm[:, None, :], axis=2)
+    dists[ok.T] = d.T[ok.T]
+    acc = np.zeros(j + 1)
+    avg, cnt = 0.0, 0
+    for i in range(j):
+        valid = dists[i] != -1
+        acc[i + 1] = (dists[i][valid] < thr).sum() * 1.0 / valid.sum() if valid.sum() > 0 else -1
+        if acc[i + 1] >= 0:
+            avg += acc[i + 1]
+            cnt += 1
+    avg = avg / cnt if cnt else 0
+    if cnt:
+        acc[0] = avg
+    return acc, avg, cnt, pred
+
+
 def train(config, train_loader, model, criterion=None, optimizer=None, epoch=0, output_dir=None, tb_log_dir=None,
           writer_dict=None, world_size=1):
     """function.py:27-111.  Returns the sample-weighted mean loss of the epoch (what ``losses.avg`` holds)."""

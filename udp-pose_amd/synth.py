@@ -402,3 +402,19 @@ def synth_person_sets(n_images, seed=0, num_joints=17):
                 scores.append(float(rng.uniform(0.3, 1.0)))
         offs.append(len(kpts))
     return (np.stack(kpts), np.array(areas, np.float64), np.array(scores, np.float64), np.array(offs, np.int32))
+
+
+def synth_accuracy_case(seed, max_shift, n=4, j=17, h=64, w=48):
+    """(prediction, target) heat-maps for the PCK accuracy check: the prediction is the target with every
+    (image, joint) map rolled by its own random shift of up to ``max_shift`` pixels, plus noise; joint 3 of
+    image 0 is absent (all-zero target)."""
+    rng = np.random.default_rng(seed)
+    tgt = synth_heatmaps(n, j, h, w, seed=seed)
+    pred = np.empty_like(tgt)
+    for a in range(n):
+        for b in range(j):
+            dy, dx = rng.integers(-max_shift, max_shift + 1, 2)
+            pred[a, b] = np.roll(tgt[a, b], (int(dy), int(dx)), axis=(0, 1))
+    pred += 0.01 * rng.standard_normal(pred.shape).astype(np.float32)
+    tgt[0, 3] = 0.0
+    return pred, tgt
