@@ -941,6 +941,85 @@ __global__ __launch_bounds__(256, 4) void stem_conv_kernel(const ConvParams p) {
   }
 }
 
+// bf16 stem on the matrix pipe: conv1 as a GEMM with K = 27 taps*channels (padded to 32).  No LDS: a lane
+// gathers the 8 K-values of its pixel straight from the NCHW fp32 input (neighbouring pixels share cache
+// lines), splits each into bf16 hi + lo (the input keeps ~16 bits through two MFMAs), the 64 x 32 weight
+// block lives in registers.  HBM-bound (75 MB in, 201 MB out at batch 128) instead of VALU-bound.
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const ConvParams p) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kg = lane >> 4;
+  const float* wg = reinterpret_cast<const float*>(p.wgt);
+  bf16x8 wf[4];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+    const int cout = 16 * (li >> 2) + 4 * nb + (li & 3);       // row li of tile nb (the lane-owns-16-couts permutation)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 8 * kg + j;
+      wf[nb][j] = (__bf16)(k < 27 ? wg[k * 64 + cout] : 0.f);
+    }
+  }
+  const int cbase = 16 * kg;
+  f32x4 bias[4];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) bias[nb] = *reinterpret_cast<const f32x4*>(p.bias + cbase + 4 * nb);
+  int koff[8];                                                // dy+1 | (dx+1) << 2 | ch << 4, -1 = padding k
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = 8 * kg + j, tap = k / 3;
+    koff[j] = k < 27 ? ((tap / 3) | ((tap % 3) << 2) | ((k % 3) << 4)) : -1;
+  }
+  const long total = (long)p.N * p.Hout * p.Wout;
+  const long ntile = (total + 15) / 16;
+  const size_t plane = (size_t)p.Hin * p.Win;
+  for (long tile = (long)blockIdx.x * 4 + wave; tile < ntile; tile += (long)gridDim.x * 4) {
+    const long pix = tile * 16 + li;
+    const bool okp = pix < total;
+    const long pp = okp ? pix : total - 1;
+    const int xo = pp % p.Wout;
+    const long t2 = pp / p.Wout;
+    const int yo = t2 % p.Hout;
+    const int n = t2 / p.Hout;
+    const bool mirror = n >= p.flip_from;
+    const float* in = reinterpret_cast<const float*>(p.in) + (size_t)(mirror ? n - p.flip_from : n) * 3 * plane;
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ko = koff[j];
+      const int gy = yo * 2 - 1 + (ko & 3), gx = xo * 2 - 1 + ((ko >> 2) & 3);
+      const bool ok = ko >= 0 && gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win;
+      const int sx = mirror ? p.Win - 1 - gx : gx;
+      const float v = ok ? in[(size_t)(ko >> 4) * plane + (size_t)gy * p.Win + sx] : 0.f;
+      hi[j] = (__bf16)v;
+      lo[j] = (__bf16)(v - (float)hi[j]);
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb], hi, bias[nb], 0, 0, 0);
+      acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb], lo, acc[nb], 0, 0, 0);
+    }
+    if (okp) {
+      __bf16* o = reinterpret_cast<__bf16*>(p.out) + (size_t)pix * 64 + cbase;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        bf16x8 ov;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float a = acc[2 * h][q], b = acc[2 * h + 1][q];
+          if (p.relu) {
+            a = a > 0.f ? a : 0.f;
+            b = b > 0.f ? b : 0.f;
+          }
+          ov[q] = (__bf16)a;
+          ov[4 + q] = (__bf16)b;
+        }
+        *reinterpret_cast<bf16x8*>(o + 8 * h) = ov;
+      }
+    }
+  }
+}
+
 // Exchange-unit output for the highest-resolution branch when it has no conv
 // term: out = relu(x_i + sum_k nearest_up(T_ik)), pose_hrnet.py:267-272 with the
 // identity f_ii of :222-223.
@@ -1408,6 +1487,15 @@ int describe_multi(const Launch* members, int n, ConvMulti* m, Launch* out) {
 int describe_stem(const ConvParams& p, int dtype, Launch* out) {
   if (p.Cout != 64) return fail(UDP_ERR_UNSUPPORTED, "stem conv expects 64 output channels, got %d", p.Cout);
   const long total = (long)p.N * p.Hout * p.Wout;
+  if (dtype == UDP_BF16 && getenv("UDP_POSE_STEM_VALU") == nullptr) {
+    const long ntile = (total + 15) / 16;
+    out->fn = reinterpret_cast<const void*>(&stem_mfma_kernel);
+    out->grid = dim3((unsigned)((ntile + 3) / 4 < 4096 ? (ntile + 3) / 4 : 4096));
+    out->block = dim3(256);
+    out->lds = 0;
+    out->p = p;
+    return UDP_OK;
+  }
   out->fn = dtype == UDP_F32 ? reinterpret_cast<const void*>(&stem_conv_kernel<float>)
                              : reinterpret_cast<const void*>(&stem_conv_kernel<__bf16>);
   out->grid = dim3((unsigned)((total + 63) / 64));
