@@ -1424,7 +1424,7 @@ int describe_conv(ConvParams p, int dtype, int ks, int stride, Launch* out) {
 // into a conv_mfma_multi node): every member uses the instantiation <bf16, 3, 1, NB=2, MBW=4, 4 waves>.
 // Returns 1 when the conv does not qualify (the caller falls back to describe_conv).
 int describe_conv_grouped(ConvParams p, int dtype, int ks, int stride, Launch* out) {
-  if (dtype != UDP_BF16 || (ks != 3 && ks != 1) || stride != 1 || p.out_nchw_f32 || p.nup || p.Cin % 32 || p.Cout % 32) return 1;
+  if (dtype != UDP_BF16 || (ks != 3 && ks != 1) || stride != 1 || p.out_nchw_f32 || p.nup || p.Cin % 16 || p.Cout % 16 || p.CoutPad % 32) return 1;
   if ((size_t)p.N * p.Hin * p.Win * p.in_pitch * 2 >= 0x7FFF0000u || (p.in_coff * 2) % 16 || (p.in_pitch * 2) % 16 ||
       (p.out_coff * 2) % 16 || (p.out_pitch * 2) % 16 || (p.res && ((p.res_coff * 2) % 16 || (p.res_pitch * 2) % 16)) || p.N >= 2048)
     return 1;
