@@ -34,7 +34,9 @@ from udp_pose_amd.model import MODELS  # noqa: E402
 from udp_pose_amd.transforms import COCO_FLIP_PAIRS, channel_map  # noqa: E402
 from udp_pose_amd import _lib  # noqa: E402
 
-PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # dense MFMA peaks, MI355X_MICROARCH.md
+# dense MFMA peaks, MI355X_MICROARCH.md.  f16x2 (split fp16) issues three fp16 MFMAs per algorithmic
+# product, so its ceiling in ALGORITHMIC FLOP/s is the fp16 peak / 3
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "f16x2": 2500.0 / 3}
 PEAK_HBM_GBS = 8000.0
 
 
@@ -216,7 +218,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=0, help="crops per GPU per step (default 64; 32 for w48)")
     ap.add_argument("--model", default="w32", choices=sorted(MODELS_CFG), help="w32 256x192 (headline), w48 384x288, rsn18 256x192 + offset head/decode")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f16x2"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches on lane streams instead of hipGraph replay")
     args = ap.parse_args()

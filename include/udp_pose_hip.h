@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UDP_POSE_ABI_VERSION 11
+#define UDP_POSE_ABI_VERSION 12
 
 enum udp_status {
   UDP_OK = 0,
@@ -35,7 +35,14 @@ enum udp_status {
   UDP_ERR_WORKSPACE = -4     /* workspace too small */
 };
 
-enum udp_dtype { UDP_F32 = 0, UDP_BF16 = 1 }; /* storage type of activations + weights */
+/* Storage type of activations + weights.
+ *   UDP_F32   fp32, exact fp32 MFMA (v_mfma_f32_16x16x4_f32): the reference's arithmetic.
+ *   UDP_BF16  bf16 storage, fp32 accumulate: reduced precision (does NOT meet the 1e-3 parity contract).
+ *   UDP_F16X2 split fp16: a value is the pair (hi, lo) with x ~= hi + lo * 2^-11 (22 significant bits),
+ *             4 bytes per element laid out per pixel as [C hi][C lo]; products run as three fp16 MFMAs
+ *             with fp32 accumulation.  The parity-grade throughput mode (fp32-level results, fp16 matrix
+ *             pipe).  |x| >= 65520 overflows to NaN (never silently). */
+enum udp_dtype { UDP_F32 = 0, UDP_BF16 = 1, UDP_F16X2 = 2 };
 
 /* ABI version of the loaded library (== UDP_POSE_ABI_VERSION it was built with). */
 int udp_abi_version(void);

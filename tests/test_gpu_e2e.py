@@ -97,6 +97,22 @@ def test_w32_fp32_matches_reference_heatmaps(golden_dir, w32_gaussian):
     np.testing.assert_array_equal(got.reshape(2, 17, -1).argmax(2), ref_idx)   # arg-max bit-exact
 
 
+def test_w32_f16x2_matches_reference_heatmaps(golden_dir, w32_gaussian):
+    """Config 2 network in the split-fp16 throughput mode (three fp16 MFMAs per product, 22-bit operands,
+    fp32 accumulate): the SAME gate as the fp32 mode -- north-star 1e-3 and arg-max bit-exact -- on the two
+    crops whose heat-maps the REFERENCE module produced."""
+    sd, _ = w32_gaussian
+    g = np.load(os.path.join(golden_dir, "hrnet_w32_gaussian.npz"))
+    net = MODELS["pose_hrnet"](_cfg(synth.W32_EXTRA, 17, "gaussian"), is_train=False, dtype="f16x2")
+    net.load_state_dict(sd).to("cuda")
+    x = torch.from_numpy(synth.synth_crops(2, 256, 192, seed=5)).cuda()
+    got = net(x).clone().cpu().numpy()
+    err = np.abs(got - g["out"]).max()
+    print("w32 f16x2 max abs heat-map error vs reference: %.3g (absmax %.3g)" % (err, np.abs(g["out"]).max()))
+    np.testing.assert_allclose(got, g["out"], rtol=0, atol=1e-3)
+    np.testing.assert_array_equal(got.reshape(2, 17, -1).argmax(2), g["out"].reshape(2, 17, -1).argmax(2))
+
+
 def test_w32_offset_head_matches_reference_heatmaps(golden_dir):
     sd = _w32(golden_dir, "offset")
     net = MODELS["pose_hrnet"](_cfg(synth.W32_EXTRA, 17, "offset"), is_train=False).load_state_dict(sd).to("cuda")

@@ -20,6 +20,7 @@ from oracle import decode as odec           # noqa: E402
 from oracle import flip as oflip            # noqa: E402
 from oracle import loss as oloss            # noqa: E402
 from udp_pose_amd import _lib, synth        # noqa: E402
+from udp_pose_amd import f16x2              # noqa: E402
 from udp_pose_amd import inference as uinf  # noqa: E402
 from udp_pose_amd import transforms as utr  # noqa: E402
 
@@ -38,13 +39,15 @@ def _adversarial(hm, k):
 def _conv_case(dtype, ks, stride, cin, cout, h, w, n, relu, res, nup, nchw_out=False, seed=0):
     rng = np.random.Generator(np.random.PCG64(seed))
     tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    h2 = dtype == "f16x2"
+    q = (lambda t: f16x2.decode(f16x2.encode(t))) if h2 else (lambda t: t)     # operands exactly as the device holds them
     pad = ks // 2
     ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
-    x = torch.from_numpy(rng.standard_normal((n, cin, h, w)).astype(np.float32)).to(tdt)
-    wt = torch.from_numpy((rng.standard_normal((cout, cin, ks, ks)) * np.sqrt(2.0 / (cin * ks * ks))).astype(np.float32)).to(tdt)
+    x = q(torch.from_numpy(rng.standard_normal((n, cin, h, w)).astype(np.float32)).to(tdt))
+    wt = q(torch.from_numpy((rng.standard_normal((cout, cin, ks, ks)) * np.sqrt(2.0 / (cin * ks * ks))).astype(np.float32)).to(tdt))
     bias = torch.from_numpy(rng.standard_normal(cout).astype(np.float32) * 0.1)
-    r = torch.from_numpy(rng.standard_normal((n, cout, ho, wo)).astype(np.float32)).to(tdt) if res else None
-    ups = [torch.from_numpy(rng.standard_normal((n, cout, ho >> (u + 1), wo >> (u + 1))).astype(np.float32)).to(tdt)
+    r = q(torch.from_numpy(rng.standard_normal((n, cout, ho, wo)).astype(np.float32)).to(tdt)) if res else None
+    ups = [q(torch.from_numpy(rng.standard_normal((n, cout, ho >> (u + 1), wo >> (u + 1))).astype(np.float32)).to(tdt))
            for u in range(nup)]
     # reference: stock fp32 conv on the (possibly bf16-rounded) operands
     y = F.conv2d(x.float(), wt.float(), bias, stride=stride, padding=pad)
@@ -60,8 +63,8 @@ def _conv_case(dtype, ks, stride, cin, cout, h, w, n, relu, res, nup, nchw_out=F
     wp[:, :cout] = wt.permute(2, 3, 0, 1).reshape(ks * ks, cout, cin)
     bp = torch.zeros(cout_pad)
     bp[:cout] = bias
-    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
-    d_x, d_w, d_b = nhwc(x), wp.cuda(), bp.cuda()
+    nhwc = lambda t: (f16x2.encode(t.permute(0, 2, 3, 1)) if h2 else t.permute(0, 2, 3, 1).contiguous()).cuda()
+    d_x, d_w, d_b = nhwc(x), (f16x2.encode(wp) if h2 else wp).cuda(), bp.cuda()
     d_r = nhwc(r) if r is not None else None
     d_u = [nhwc(t) for t in ups] + [None] * (3 - nup)
     op = _lib.ConvOp()
@@ -74,14 +77,16 @@ def _conv_case(dtype, ks, stride, cin, cout, h, w, n, relu, res, nup, nchw_out=F
     if nchw_out:
         op.out_buf = _lib.UDP_BUF_OUTPUT
         out = torch.full((n, cout, ho, wo), float("nan"), dtype=torch.float32, device="cuda")
+    elif h2:
+        out = torch.full((n, ho, wo, 2, cout), float("nan"), dtype=torch.float16, device="cuda")
     else:
         out = torch.full((n, ho, wo, cout), float("nan"), dtype=tdt, device="cuda")
-    _lib.check(_lib.lib().udp_conv2d_fused(C.byref(op), _lib.UDP_BF16 if dtype == "bf16" else _lib.UDP_F32, n,
+    _lib.check(_lib.lib().udp_conv2d_fused(C.byref(op), _lib.DTYPES[dtype], n,
                                            _lib.ptr(d_x), _lib.ptr(d_w), _lib.ptr(d_b), _lib.ptr(d_r),
                                            _lib.ptr(d_u[0]), _lib.ptr(d_u[1]), _lib.ptr(d_u[2]), _lib.ptr(out),
                                            _lib.stream_ptr()))
     torch.cuda.synchronize()
-    got = out.float().cpu()
+    got = (f16x2.decode(out) if h2 and not nchw_out else out.float()).cpu()
     if not nchw_out:
         got = got.permute(0, 3, 1, 2)
     return got.numpy(), y.numpy()
@@ -110,24 +115,28 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "f16x2", "bf16"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "k%ds%d_%d-%d_%dx%d_n%d" % c[:7])
 def test_fused_conv_matches_torch_fp32(case, dtype):
     got, ref = _conv_case(dtype, *case)
     assert not np.isnan(got).any(), "output not fully written"
     scale = max(1.0, float(np.abs(ref).max()))
-    # fp32: exact-fp32 MFMA, only the summation order differs.  bf16: operands are bf16-exact in
-    # both, error = fp32 accumulation order + one bf16 rounding of the output (2^-9 relative).
-    tol = 1e-4 * scale if dtype == "f32" else 6e-3 * scale
+    # fp32: exact-fp32 MFMA, only the summation order differs.  f16x2: operands are exact in both (22-bit
+    # hi + lo pairs); three fp16 MFMAs per product drop the lo*lo term (2^-22 relative), fp32 accumulate, the
+    # output is rounded to 22 bits -> same gate as fp32.  bf16: operands are bf16-exact in both, error =
+    # fp32 accumulation order + one bf16 rounding of the output (2^-9 relative).
+    tol = 6e-3 * scale if dtype == "bf16" else 1e-4 * scale
     np.testing.assert_allclose(got, ref, rtol=0, atol=tol)
+    if dtype == "f16x2":
+        assert np.abs(got - ref).max() <= 2e-5 * scale, np.abs(got - ref).max()
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "f16x2", "bf16"])
 def test_final_layer_nchw_output(dtype):
     got, ref = _conv_case(dtype, 1, 1, 128, 17, 64, 48, 3, False, False, 0, nchw_out=True)
-    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-4 if dtype == "f32" else 2e-2)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-2 if dtype == "bf16" else 1e-4)
     got, ref = _conv_case(dtype, 1, 1, 128, 51, 64, 48, 2, False, False, 0, nchw_out=True, seed=4)
-    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-4 if dtype == "f32" else 2e-2)
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-2 if dtype == "bf16" else 1e-4)
 
 
 def test_conv_rejects_bad_shapes():

@@ -11,11 +11,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libudp_pose_hip.so")
 
 UDP_OK = 0
-UDP_F32, UDP_BF16 = 0, 1
+UDP_F32, UDP_BF16, UDP_F16X2 = 0, 1, 2
+DTYPES = {"f32": UDP_F32, "bf16": UDP_BF16, "f16x2": UDP_F16X2}
 UDP_OP_STEM, UDP_OP_CONV, UDP_OP_FUSE, UDP_OP_STEM7, UDP_OP_MAXPOOL, UDP_OP_BILINEAR = 0, 1, 2, 3, 4, 5
 UDP_OP_PSA_POOL, UDP_OP_PSA_MLP, UDP_OP_PSA_SCALE, UDP_OP_PSA_SP, UDP_OP_BLOCK = 6, 7, 8, 9, 10
 UDP_BUF_NONE, UDP_BUF_OUTPUT = -1, -2
-ABI_VERSION = 11
+ABI_VERSION = 12
 MAX_LANES, MAX_WAIT = 4, 8
 
 

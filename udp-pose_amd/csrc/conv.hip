@@ -33,6 +33,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// Split-fp16 storage ("f16x2", UDP_F16X2): a value x is kept as two fp16 numbers, x ~= hi + lo * 2^-11 with
+// hi = fp16(x) and lo = fp16((x - hi) * 2^11): 22 significant bits over fp16's whole normal range (the
+// scaled lo never goes subnormal before hi does).  A product of two such numbers runs as three fp16 MFMAs
+// (hi*hi into the main accumulator; hi*lo and lo*hi into a second one that is folded in with 2^-11 at the
+// end; lo*lo ~ 2^-22 is dropped), i.e. fp32-grade results on the 2.5 PF fp16 matrix pipe instead of the
+// 157 TF fp32 one.  Memory layout: per pixel (or weight row) the C hi values, then the C lo values.
+struct H2 {};
+constexpr float kLoScale = 2048.f, kLoInv = 1.f / 2048.f;
 
 constexpr int ROWB = 64;   // LDS row: one pixel's (or one weight row's) 64-byte channel chunk
 constexpr int MAXG = 10;   // 16-row staging groups per wave for the input tile (<= 640 rows)
@@ -80,69 +91,96 @@ struct Tr;
 template <>
 struct Tr<float> {
   static constexpr int CK = 16;  // input channels per LDS chunk (64 B)
+  static constexpr int ESZ = 4;  // bytes per element of one plane
+  static constexpr int PL = 1;   // planes per element (H2: hi, lo)
 };
 template <>
 struct Tr<__bf16> {
   static constexpr int CK = 32;
+  static constexpr int ESZ = 2;
+  static constexpr int PL = 1;
+};
+template <>
+struct Tr<H2> {
+  static constexpr int CK = 32;
+  static constexpr int ESZ = 2;
+  static constexpr int PL = 2;
 };
 
+// 4 consecutive channels c..c+3 of pixel `pix` of an NHWC tensor with `pitch` channels per pixel
 template <typename T>
-__device__ __forceinline__ f32x4 load4(const T* p);
-template <>
-__device__ __forceinline__ f32x4 load4<float>(const float* p) {
-  return *reinterpret_cast<const f32x4*>(p);
-}
-template <>
-__device__ __forceinline__ f32x4 load4<__bf16>(const __bf16* p) {
-  bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
-  return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+__device__ __forceinline__ f32x4 ld4(const void* base, size_t pix, int pitch, int c) {
+  if constexpr (std::is_same<T, float>::value) {
+    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + pix * pitch + c);
+  } else if constexpr (std::is_same<T, __bf16>::value) {
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(base) + pix * pitch + c);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+  } else {
+    const _Float16* q = reinterpret_cast<const _Float16*>(base) + pix * (2 * (size_t)pitch) + c;
+    const f16x4 hi = *reinterpret_cast<const f16x4*>(q), lo = *reinterpret_cast<const f16x4*>(q + pitch);
+    return f32x4{(float)hi[0] + (float)lo[0] * kLoInv, (float)hi[1] + (float)lo[1] * kLoInv,
+                 (float)hi[2] + (float)lo[2] * kLoInv, (float)hi[3] + (float)lo[3] * kLoInv};
+  }
 }
 template <typename T>
-__device__ __forceinline__ void store4(T* p, f32x4 v);
-template <>
-__device__ __forceinline__ void store4<float>(float* p, f32x4 v) {
-  *reinterpret_cast<f32x4*>(p) = v;
-}
-template <>
-__device__ __forceinline__ void store4<__bf16>(__bf16* p, f32x4 v) {
-  bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-  *reinterpret_cast<bf16x4*>(p) = o;
+__device__ __forceinline__ void st4(void* base, size_t pix, int pitch, int c, f32x4 v) {
+  if constexpr (std::is_same<T, float>::value) {
+    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + pix * pitch + c) = v;
+  } else if constexpr (std::is_same<T, __bf16>::value) {
+    const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(base) + pix * pitch + c) = o;
+  } else {
+    _Float16* q = reinterpret_cast<_Float16*>(base) + pix * (2 * (size_t)pitch) + c;
+    f16x4 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      hi[k] = (_Float16)v[k];
+      lo[k] = (_Float16)((v[k] - (float)hi[k]) * kLoScale);
+    }
+    *reinterpret_cast<f16x4*>(q) = hi;
+    *reinterpret_cast<f16x4*>(q + pitch) = lo;
+  }
 }
 
-// 4*NB consecutive channels <-> NB accumulator tiles of one lane
+// split / join of the H2 form for 8 consecutive channels held as two accumulator quads
+__device__ __forceinline__ void h2_split8(const f32x4& a, const f32x4& b, f16x8& hi, f16x8& lo) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    hi[q] = (_Float16)a[q];
+    hi[4 + q] = (_Float16)b[q];
+    lo[q] = (_Float16)((a[q] - (float)hi[q]) * kLoScale);
+    lo[4 + q] = (_Float16)((b[q] - (float)hi[4 + q]) * kLoScale);
+  }
+}
+__device__ __forceinline__ void h2_add8(f32x4& a, f32x4& b, const f16x8 hi, const f16x8 lo) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    a[q] += (float)hi[q] + (float)lo[q] * kLoInv;
+    b[q] += (float)hi[4 + q] + (float)lo[4 + q] * kLoInv;
+  }
+}
+
+// 4*NB consecutive channels <-> NB accumulator tiles of one lane.  `p` points at the lane's first
+// channel (bytes); H2: the lo plane starts lo_off bytes further
 template <typename T, int NB>
-__device__ __forceinline__ void add_vec(f32x4 (&v)[NB], const T* p) {
+__device__ __forceinline__ void add_vec(f32x4 (&v)[NB], const unsigned char* p, unsigned lo_off) {
   if constexpr (std::is_same<T, float>::value) {
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) v[nb] += *reinterpret_cast<const f32x4*>(p + 4 * nb);
-  } else {
+    for (int nb = 0; nb < NB; ++nb) v[nb] += *reinterpret_cast<const f32x4*>(p + 16 * nb);
+  } else if constexpr (std::is_same<T, __bf16>::value) {
 #pragma unroll
     for (int h = 0; h < NB / 2; ++h) {
-      const bf16x8 x = *reinterpret_cast<const bf16x8*>(p + 8 * h);
+      const bf16x8 x = *reinterpret_cast<const bf16x8*>(p + 16 * h);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         v[2 * h][q] += (float)x[q];
         v[2 * h + 1][q] += (float)x[4 + q];
       }
     }
-  }
-}
-template <typename T, int NB>
-__device__ __forceinline__ void store_vec(T* p, const f32x4 (&v)[NB]) {
-  if constexpr (std::is_same<T, float>::value) {
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) *reinterpret_cast<f32x4*>(p + 4 * nb) = v[nb];
   } else {
 #pragma unroll
-    for (int h = 0; h < NB / 2; ++h) {
-      bf16x8 o;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        o[q] = (__bf16)v[2 * h][q];
-        o[4 + q] = (__bf16)v[2 * h + 1][q];
-      }
-      *reinterpret_cast<bf16x8*>(p + 8 * h) = o;
-    }
+    for (int h = 0; h < NB / 2; ++h)
+      h2_add8(v[2 * h], v[2 * h + 1], *reinterpret_cast<const f16x8*>(p + 16 * h), *reinterpret_cast<const f16x8*>(p + lo_off + 16 * h));
   }
 }
 
@@ -161,11 +199,18 @@ __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t r, unsigned voff, 
 // 4*NB consecutive channels of one pixel <-> the NB accumulator tiles of a lane, through a buffer
 // descriptor: masked lanes pass kOobOff (loads return 0, stores are dropped) -> no branches
 template <typename T, int NB>
-__device__ __forceinline__ void add_vec_buf(f32x4 (&v)[NB], __amdgpu_buffer_rsrc_t r, unsigned voff) {
+__device__ __forceinline__ void add_vec_buf(f32x4 (&v)[NB], __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned lo_off) {
   if constexpr (std::is_same<T, float>::value) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
       v[nb] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff + 16 * nb, 0, 0));
+  } else if constexpr (std::is_same<T, H2>::value) {
+#pragma unroll
+    for (int h = 0; h < NB / 2; ++h) {
+      const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(r, voff + 16 * h, 0, 0);
+      const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(r, voff + lo_off + 16 * h, 0, 0);
+      h2_add8(v[2 * h], v[2 * h + 1], __builtin_bit_cast(f16x8, hi), __builtin_bit_cast(f16x8, lo));
+    }
   } else {
 #pragma unroll
     for (int h = 0; h < NB / 2; ++h) {
@@ -210,11 +255,19 @@ __device__ __forceinline__ void add_res_regs(f32x4 (&v)[NB], const ResRegs<T, NB
   }
 }
 template <typename T, int NB>
-__device__ __forceinline__ void store_vec_buf(__amdgpu_buffer_rsrc_t r, unsigned voff, const f32x4 (&v)[NB]) {
+__device__ __forceinline__ void store_vec_buf(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned lo_off, const f32x4 (&v)[NB]) {
   if constexpr (std::is_same<T, float>::value) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[nb]), r, voff + 16 * nb, 0, 0);
+  } else if constexpr (std::is_same<T, H2>::value) {
+#pragma unroll
+    for (int h = 0; h < NB / 2; ++h) {
+      f16x8 hi, lo;
+      h2_split8(v[2 * h], v[2 * h + 1], hi, lo);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi), r, voff + 16 * h, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo), r, voff + lo_off + 16 * h, 0, 0);
+    }
   } else {
 #pragma unroll
     for (int h = 0; h < NB / 2; ++h) {
@@ -274,11 +327,57 @@ __device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[MBW][NB], const unsigned
   }
 }
 
+// The same for split-fp16 operands: the hi / lo images of the input tile lie in_lo bytes apart in LDS, those
+// of the weights w_lo bytes; per (pixel block, cout block) and tap three v_mfma_f32_16x16x32_f16:
+//   acc  += Whi * Xhi            accx += Whi * Xlo + Wlo * Xhi      (result = acc + 2^-11 accx)
+template <int KS, int NB, int MBW>
+__device__ __forceinline__ void mfma_chunk_h2(f32x4 (&acc)[MBW][NB], f32x4 (&accx)[MBW][NB], const unsigned char* sb,
+                                              const unsigned char* wrow, int in_lo, int w_lo, const int (&prow)[MBW],
+                                              int IW, int kg, int wswz) {
+  constexpr int BN = NB * 16;
+  constexpr int NSTEP = KS * KS;
+  f16x8 wh[2][NB], wl[2][NB], xh[2][MBW], xl[2][MBW];
+  auto load = [&](int tap, f16x8 (&a)[NB], f16x8 (&b)[NB], f16x8 (&c)[MBW], f16x8 (&d)[MBW]) {
+    const int tap_rows = (tap / KS) * IW + tap % KS;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const unsigned char* q = wrow + (tap * BN + nb * 16) * ROWB + ((kg ^ wswz) << 4);
+      a[nb] = *reinterpret_cast<const f16x8*>(q);
+      b[nb] = *reinterpret_cast<const f16x8*>(q + w_lo);
+    }
+#pragma unroll
+    for (int i = 0; i < MBW; ++i) {
+      const int row = prow[i] + tap_rows;
+      const unsigned char* q = sb + row * ROWB + ((kg ^ swz<H2>(row)) << 4);
+      c[i] = *reinterpret_cast<const f16x8*>(q);
+      d[i] = *reinterpret_cast<const f16x8*>(q + in_lo);
+    }
+  };
+  load(0, wh[0], wl[0], xh[0], xl[0]);
+#pragma unroll
+  for (int s = 0; s < NSTEP; ++s) {
+    if (s + 1 < NSTEP) load(s + 1, wh[(s + 1) & 1], wl[(s + 1) & 1], xh[(s + 1) & 1], xl[(s + 1) & 1]);
+#pragma unroll
+    for (int i = 0; i < MBW; ++i)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s & 1][nb], xh[s & 1][i], acc[i][nb], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < MBW; ++i)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) accx[i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[s & 1][nb], xl[s & 1][i], accx[i][nb], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < MBW; ++i)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) accx[i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[s & 1][nb], xh[s & 1][i], accx[i][nb], 0, 0, 0);
+  }
+}
+
 // MBW = 16-pixel blocks per wave (ceil(M/64)); NCHW = epilogue writes the fp32 NCHW network output.
 template <typename T, int KS, int STRIDE, int NB, int MBW, bool NCHW, int NW>
 __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int tile_id, const int cb) {
   constexpr int CK = Tr<T>::CK;
-  constexpr int ESZ = (int)sizeof(T);
+  constexpr int ESZ = Tr<T>::ESZ;
+  constexpr int PL = Tr<T>::PL;
   constexpr int BN = NB * 16;
   constexpr int PAD = KS / 2;
   constexpr int TAPS = KS * KS;
@@ -304,14 +403,17 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int ti
   const int npix_in = p.G * IH * IW;
   const int in_groups = (npix_in + 15) >> 4;
   const int in_bytes = in_groups * 16 * ROWB;
-  const int stage_bytes = in_bytes + TAPS * BN * ROWB;
+  constexpr int W_BYTES = TAPS * BN * ROWB;           // one plane of the weight block
+  const int stage_bytes = PL * (in_bytes + W_BYTES);  // [input planes][weight planes]
   const int nchunks = (p.Cin + CK - 1) / CK;
   const bool ragged = (p.Cin % CK) != 0;   // last chunk is partly past Cin: those 16-byte parts read zeros
   const int RT = p.R * p.TW;
   const int M = p.G * RT;
-  const unsigned cinb = (unsigned)p.Cin * ESZ;          // weight row
-  const unsigned inpb = (unsigned)p.in_pitch * ESZ;     // input pixel (the conv may read a channel slice)
-  const unsigned outpb = (unsigned)p.out_pitch * ESZ, respb = (unsigned)p.res_pitch * ESZ;
+  const unsigned cinb = (unsigned)p.Cin * ESZ * PL;          // weight row (H2: hi plane, then lo plane)
+  const unsigned inpb = (unsigned)p.in_pitch * ESZ * PL;     // input pixel (the conv may read a channel slice)
+  const unsigned outpb = (unsigned)p.out_pitch * ESZ * PL, respb = (unsigned)p.res_pitch * ESZ * PL;
+  const unsigned w_lo = (unsigned)p.Cin * ESZ, in_lo = (unsigned)p.in_pitch * ESZ;   // lo plane offsets (H2)
+  const unsigned out_lo = (unsigned)p.out_pitch * ESZ, res_lo = (unsigned)p.res_pitch * ESZ;
 
   const unsigned out_pix = (unsigned)p.N * p.Hout * p.Wout;
   const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(
@@ -356,6 +458,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int ti
         unsigned off = src_off[i] + coff;
         if (cut && (spart ^ swz<T>(gidx * 16 + srow)) >= parts_left) off = kOobOff;
         blds16(r_in, off, sb + gidx * (16 * ROWB));
+        if constexpr (PL == 2) blds16(r_in, off + in_lo, sb + in_bytes + gidx * (16 * ROWB));
       }
     }
     for (int gidx = wave; gidx < WGROUPS; gidx += NW) {
@@ -366,7 +469,8 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int ti
       const int lp = spart ^ swz<T>(wr);
       unsigned e = __umul24(__umul24(tap, p.CoutPad) + cb * BN + co, cinb) + coff + (lp << 4);
       if (cut && lp >= parts_left) e = kOobOff;
-      blds16(r_w, e, sb + in_bytes + gidx * (16 * ROWB));
+      blds16(r_w, e, sb + PL * in_bytes + gidx * (16 * ROWB));
+      if constexpr (PL == 2) blds16(r_w, e + w_lo, sb + PL * in_bytes + W_BYTES + gidx * (16 * ROWB));
     }
   };
 
@@ -393,6 +497,11 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int ti
   const int wswz = swz<T>(li);  // weight rows: (tap*BN + nb*16) is a multiple of 16 -> swizzle depends on li only
 
   f32x4 acc[MBW][NB];
+  f32x4 accx[PL == 2 ? MBW : 1][NB];   // H2: the 2^11-scaled cross terms
+#pragma unroll
+  for (int i = 0; i < (PL == 2 ? MBW : 1); ++i)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) accx[i][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
   {
     f32x4 bias[NB];
 #pragma unroll
@@ -412,7 +521,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int ti
     if (p.res) {
 #pragma unroll
       for (int i = 0; i < MBW; ++i)
-        add_vec_buf<T, NB>(acc[i], r_res, opix[i] >= 0 ? (unsigned)opix[i] * respb + (p.res_coff + cbase) * ESZ : kOobOff);
+        add_vec_buf<T, NB>(acc[i], r_res, opix[i] >= 0 ? (unsigned)opix[i] * respb + (p.res_coff + cbase) * ESZ : kOobOff, res_lo);
     }
   }
   UDP_STAMP(2);
@@ -425,7 +534,16 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int ti
     if (c == 0) UDP_STAMP(4);
     if (c + 1 < nchunks) stage(c + 1, smem + ((c + 1) & 1) * stage_bytes);
     const unsigned char* sb = smem + (c & 1) * stage_bytes;
-    mfma_chunk<T, KS, NB, MBW>(acc, sb, sb + in_bytes + li * ROWB, prow, IW, kg, wswz);
+    if constexpr (PL == 2)
+      mfma_chunk_h2<KS, NB, MBW>(acc, accx, sb, sb + PL * in_bytes + li * ROWB, in_bytes, W_BYTES, prow, IW, kg, wswz);
+    else
+      mfma_chunk<T, KS, NB, MBW>(acc, sb, sb + in_bytes + li * ROWB, prow, IW, kg, wswz);
+  }
+  if constexpr (PL == 2) {
+#pragma unroll
+    for (int i = 0; i < MBW; ++i)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[i][nb] += accx[i][nb] * kLoInv;
   }
 
   UDP_STAMP(5);
@@ -460,7 +578,8 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int ti
           if (u < p.nup) {
             const int s = p.up_shift[u];
             const long up_pix = ((long)(n * (p.Hout >> s) + (y >> s)) * (p.Wout >> s) + (xo >> s));
-            if (crd >= 0) add_vec<T, NB>(v, reinterpret_cast<const T*>(p.up[u]) + up_pix * p.Cout + cbase);
+            if (crd >= 0)
+              add_vec<T, NB>(v, reinterpret_cast<const unsigned char*>(p.up[u]) + (up_pix * p.Cout * PL + cbase) * ESZ, p.Cout * ESZ);
           }
         }
       }
@@ -470,7 +589,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int ti
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[nb][q] = v[nb][q] > 0.f ? v[nb][q] : 0.f;
       }
-      store_vec_buf<T, NB>(r_out, ooff, v);
+      store_vec_buf<T, NB>(r_out, ooff, out_lo, v);
     }
   }
   UDP_STAMP(6);
@@ -671,7 +790,7 @@ __global__ __launch_bounds__(256) void conv_mfma_persist1(const ConvParams p) {
           if (u < p.nup) {
             const int s = p.up_shift[u];
             const long up_pix = ((long)(n * (p.Hout >> s) + (y >> s)) * (p.Wout >> s) + (xo >> s));
-            if (ok) add_vec<T, NB>(v, reinterpret_cast<const T*>(p.up[u]) + up_pix * p.Cout + cbase);
+            if (ok) add_vec<T, NB>(v, reinterpret_cast<const unsigned char*>(p.up[u]) + (up_pix * p.Cout + cbase) * ESZ, 0);
           }
         }
       }
@@ -681,7 +800,7 @@ __global__ __launch_bounds__(256) void conv_mfma_persist1(const ConvParams p) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[nb][q] = v[nb][q] > 0.f ? v[nb][q] : 0.f;
       }
-      store_vec_buf<T, NB>(r_out, voff, v);
+      store_vec_buf<T, NB>(r_out, voff, 0, v);
     }
     // the next tile's DMA was issued before this tile's NSTORE stores: it has landed once at most
     // NSTORE memory operations are still outstanding (they complete in issue order)
@@ -929,7 +1048,6 @@ __global__ __launch_bounds__(256, 4) void stem_conv_kernel(const ConvParams p) {
       }
     }
   }
-  T* o = reinterpret_cast<T*>(p.out) + (size_t)pix * 64 + cg * 16;
 #pragma unroll
   for (int q = 0; q < 16; q += 4) {
     f32x4 v = {acc[q], acc[q + 1], acc[q + 2], acc[q + 3]};
@@ -937,7 +1055,7 @@ __global__ __launch_bounds__(256, 4) void stem_conv_kernel(const ConvParams p) {
 #pragma unroll
       for (int z = 0; z < 4; ++z) v[z] = v[z] > 0.f ? v[z] : 0.f;
     }
-    store4<T>(o + q, v);
+    st4<T>(p.out, (size_t)pix, 64, cg * 16 + q, v);
   }
 }
 
@@ -1034,18 +1152,18 @@ __global__ __launch_bounds__(256) void fuse_sum_kernel(const ConvParams p) {
     const long t2 = pix / p.Wout;
     const int y = t2 % p.Hout;
     const int n = t2 / p.Hout;
-    f32x4 v = load4<T>(reinterpret_cast<const T*>(p.in) + pix * p.in_pitch + p.in_coff + c);
-    if (p.res) v += load4<T>(reinterpret_cast<const T*>(p.res) + pix * p.res_pitch + p.res_coff + c);
+    f32x4 v = ld4<T>(p.in, (size_t)pix, p.in_pitch, p.in_coff + c);
+    if (p.res) v += ld4<T>(p.res, (size_t)pix, p.res_pitch, p.res_coff + c);
     for (int u = 0; u < p.nup; ++u) {
       const int s = p.up_shift[u];
       const size_t up_pix = ((size_t)(n * (p.Hout >> s) + (y >> s)) * (p.Wout >> s) + (xo >> s));
-      v += load4<T>(reinterpret_cast<const T*>(p.up[u]) + up_pix * p.Cout + c);
+      v += ld4<T>(p.up[u], up_pix, p.Cout, c);
     }
     if (p.relu) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.f;
     }
-    store4<T>(reinterpret_cast<T*>(p.out) + pix * p.out_pitch + p.out_coff + c, v);
+    st4<T>(p.out, (size_t)pix, p.out_pitch, p.out_coff + c, v);
   }
 }
 
@@ -1095,7 +1213,6 @@ __global__ __launch_bounds__(256, 4) void stem7_conv_kernel(const ConvParams p) 
       }
     }
   }
-  T* o = reinterpret_cast<T*>(p.out) + (size_t)pix * 64 + cg * 16;
 #pragma unroll
   for (int q = 0; q < 16; q += 4) {
     f32x4 v = {acc[q], acc[q + 1], acc[q + 2], acc[q + 3]};
@@ -1103,7 +1220,7 @@ __global__ __launch_bounds__(256, 4) void stem7_conv_kernel(const ConvParams p) 
 #pragma unroll
       for (int z = 0; z < 4; ++z) v[z] = v[z] > 0.f ? v[z] : 0.f;
     }
-    store4<T>(o + q, v);
+    st4<T>(p.out, (size_t)pix, 64, cg * 16 + q, v);
   }
 }
 
@@ -1126,12 +1243,12 @@ __global__ __launch_bounds__(256) void maxpool3_kernel(const ConvParams p) {
       for (int kx = 0; kx < 3; ++kx) {
         const int gx = xo * 2 - 1 + kx;
         if (gx < 0 || gx >= p.Win) continue;
-        const f32x4 v = load4<T>(reinterpret_cast<const T*>(p.in) + ((size_t)(n * p.Hin + gy) * p.Win + gx) * p.in_pitch + p.in_coff + c);
+        const f32x4 v = ld4<T>(p.in, (size_t)(n * p.Hin + gy) * p.Win + gx, p.in_pitch, p.in_coff + c);
 #pragma unroll
         for (int q = 0; q < 4; ++q) m[q] = v[q] > m[q] ? v[q] : m[q];
       }
     }
-    store4<T>(reinterpret_cast<T*>(p.out) + pix * p.out_pitch + p.out_coff + c, m);
+    st4<T>(p.out, (size_t)pix, p.out_pitch, p.out_coff + c, m);
   }
 }
 
@@ -1155,15 +1272,15 @@ __global__ __launch_bounds__(256) void bilinear_ac_kernel(const ConvParams p) {
     const int y1 = y0 + (y0 < p.Hin - 1 ? 1 : 0), x1 = x0 + (x0 < p.Win - 1 ? 1 : 0);
     const float ly = fy - (float)y0, lx = fx - (float)x0;
     const float hy = 1.f - ly, hx = 1.f - lx;
-    const T* base = reinterpret_cast<const T*>(p.in) + (size_t)n * p.Hin * p.Win * p.in_pitch + p.in_coff + c;
-    const f32x4 v00 = load4<T>(base + ((size_t)y0 * p.Win + x0) * p.in_pitch);
-    const f32x4 v01 = load4<T>(base + ((size_t)y0 * p.Win + x1) * p.in_pitch);
-    const f32x4 v10 = load4<T>(base + ((size_t)y1 * p.Win + x0) * p.in_pitch);
-    const f32x4 v11 = load4<T>(base + ((size_t)y1 * p.Win + x1) * p.in_pitch);
+    const size_t ib = (size_t)n * p.Hin * p.Win;
+    const f32x4 v00 = ld4<T>(p.in, ib + (size_t)y0 * p.Win + x0, p.in_pitch, p.in_coff + c);
+    const f32x4 v01 = ld4<T>(p.in, ib + (size_t)y0 * p.Win + x1, p.in_pitch, p.in_coff + c);
+    const f32x4 v10 = ld4<T>(p.in, ib + (size_t)y1 * p.Win + x0, p.in_pitch, p.in_coff + c);
+    const f32x4 v11 = ld4<T>(p.in, ib + (size_t)y1 * p.Win + x1, p.in_pitch, p.in_coff + c);
     f32x4 v;
 #pragma unroll
     for (int q = 0; q < 4; ++q) v[q] = hy * (hx * v00[q] + lx * v01[q]) + ly * (hx * v10[q] + lx * v11[q]);
-    store4<T>(reinterpret_cast<T*>(p.out) + pix * p.out_pitch + p.out_coff + c, v);
+    st4<T>(p.out, (size_t)pix, p.out_pitch, p.out_coff + c, v);
   }
 }
 
@@ -1185,6 +1302,7 @@ size_t conv_choose_tile(ConvParams& p, int ks, int stride, int dtype, int* nb_ou
   };
   const int kMaxM = (int)knob("UDP_POSE_MAXM", 256);
   const int ck = dtype == UDP_F32 ? 16 : 32;
+  const int planes = dtype == UDP_F16X2 ? 2 : 1;
   const int nstage = ceil_div(p.Cin, ck) > 1 ? 2 : 1;
   int TW = p.Wout;
   while (TW > 64) TW = (TW + 1) / 2;
@@ -1202,7 +1320,7 @@ size_t conv_choose_tile(ConvParams& p, int ks, int stride, int dtype, int* nb_ou
   int NB = (p.CoutPad % 64 == 0 && !grouped) ? 4 : 2;
   auto npix = [&](int g, int r) { return g * ((r - 1) * stride + ks) * ((TW - 1) * stride + ks); };
   auto lds = [&](int g, int r, int nb) {
-    return (size_t)(((npix(g, r) + 15) / 16) * 16 + ks * ks * nb * 16) * ROWB * nstage;
+    return (size_t)(((npix(g, r) + 15) / 16) * 16 + ks * ks * nb * 16) * ROWB * nstage * planes;
   };
   auto wgs = [&](int g, int r, int nb) {
     return (long)ceil_div(p.N, g) * ceil_div(p.Hout, r) * ceil_div(p.Wout, TW) * (p.CoutPad / (nb * 16));
@@ -1211,7 +1329,9 @@ size_t conv_choose_tile(ConvParams& p, int ks, int stride, int dtype, int* nb_ou
   const long kMinWgs = grouped ? 0 : knob("UDP_POSE_MINWGS", 512);   // a grouped launch fills the chip with its siblings
   if (wgs(G, R, NB) < kMinWgs && NB == 4) NB = 2;
   while (wgs(G, R, NB) < kMinWgs && G > 1) G = (G + 1) / 2;
-  const size_t kLimit = (size_t)knob("UDP_POSE_LDS_KB", 76) * 1024;   // 76 KB: two workgroups per CU
+  // 76 KB: two workgroups per CU.  Split-fp16 tiles are twice the bytes; the K-deep ones take the whole CU
+  // (one workgroup of 156 KB) rather than shrink below the 9*BN weight rows they are staged with
+  const size_t kLimit = (size_t)knob("UDP_POSE_LDS_KB", planes == 2 && nstage == 2 ? 156 : 76) * 1024;
   while ((lds(G, R, NB) > kLimit || npix(G, R) > MAXG * 64) && G > 1) --G;
   // stride 2: the halo tile is 4x the output pixels -- rather keep 4 cout blocks per staged tile and
   // shrink the tile (+0.4 % images/s; UDP_POSE_NO_S2_NB4 restores the old order)
@@ -1395,8 +1515,9 @@ int describe_conv(ConvParams p, int dtype, int ks, int stride, Launch* out) {
   if (p.Cin % 16 != 0) return fail(UDP_ERR_UNSUPPORTED, "conv Cin=%d is not a multiple of 16", p.Cin);
   if (!p.out_nchw_f32 && p.Cout % 16 != 0)
     return fail(UDP_ERR_UNSUPPORTED, "NHWC conv Cout=%d is not a multiple of 16", p.Cout);
-  const size_t esz = dtype == UDP_F32 ? 4 : 2;
-  if ((size_t)p.N * p.Hin * p.Win * p.in_pitch * esz >= 0x7FFF0000u || (size_t)p.N * p.Hout * p.Wout * p.out_pitch * 4 >= 0x7FFF0000u ||
+  const size_t esz = dtype == UDP_F32 ? 4 : 2;                          // bytes per element of one plane
+  const size_t pix_esz = dtype == UDP_BF16 ? 2 : 4;                     // bytes per element of a pixel (H2: two planes)
+  if ((size_t)p.N * p.Hin * p.Win * p.in_pitch * pix_esz >= 0x7FFF0000u || (size_t)p.N * p.Hout * p.Wout * p.out_pitch * 4 >= 0x7FFF0000u ||
       (p.in_coff * esz) % 16 || (p.in_pitch * esz) % 16 ||
       (!p.out_nchw_f32 && ((p.out_coff * esz) % 16 || (p.out_pitch * esz) % 16)) ||
       (p.res && ((p.res_coff * esz) % 16 || (p.res_pitch * esz) % 16)))
@@ -1417,6 +1538,7 @@ int describe_conv(ConvParams p, int dtype, int ks, int stride, Launch* out) {
     if (rc <= 0) return rc;
   }
   if (dtype == UDP_F32) return describe_conv_t<float>(p, ks, stride, nb, mbw, lds, out);
+  if (dtype == UDP_F16X2) return describe_conv_t<H2>(p, ks, stride, nb, mbw, lds, out);
   return describe_conv_t<__bf16>(p, ks, stride, nb, mbw, lds, out);
 }
 
@@ -1496,8 +1618,9 @@ int describe_stem(const ConvParams& p, int dtype, Launch* out) {
     out->p = p;
     return UDP_OK;
   }
-  out->fn = dtype == UDP_F32 ? reinterpret_cast<const void*>(&stem_conv_kernel<float>)
-                             : reinterpret_cast<const void*>(&stem_conv_kernel<__bf16>);
+  out->fn = dtype == UDP_F32     ? reinterpret_cast<const void*>(&stem_conv_kernel<float>)
+            : dtype == UDP_F16X2 ? reinterpret_cast<const void*>(&stem_conv_kernel<H2>)
+                                 : reinterpret_cast<const void*>(&stem_conv_kernel<__bf16>);
   out->grid = dim3((unsigned)((total + 63) / 64));
   out->block = dim3(256);
   out->lds = 0;
@@ -1510,8 +1633,9 @@ int describe_fuse(const ConvParams& p, int dtype, Launch* out) {
   const long total = (long)p.N * p.Hout * p.Wout * (p.Cout / 4);
   long blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  out->fn = dtype == UDP_F32 ? reinterpret_cast<const void*>(&fuse_sum_kernel<float>)
-                             : reinterpret_cast<const void*>(&fuse_sum_kernel<__bf16>);
+  out->fn = dtype == UDP_F32     ? reinterpret_cast<const void*>(&fuse_sum_kernel<float>)
+            : dtype == UDP_F16X2 ? reinterpret_cast<const void*>(&fuse_sum_kernel<H2>)
+                                 : reinterpret_cast<const void*>(&fuse_sum_kernel<__bf16>);
   out->grid = dim3((unsigned)blocks);
   out->block = dim3(256);
   out->lds = 0;
@@ -1526,13 +1650,14 @@ extern "C" int udp_debug_set_stamps(unsigned long long* dev_buf) {
 }
 #endif
 
-template <typename KF, typename KB>
-static int describe_elementwise(const ConvParams& p, int dtype, KF kf, KB kb, Launch* out) {
+template <typename KF, typename KB, typename KH>
+static int describe_elementwise(const ConvParams& p, int dtype, KF kf, KB kb, KH kh, Launch* out) {
   if (p.Cout % 4 != 0) return fail(UDP_ERR_UNSUPPORTED, "element-wise op: C=%d is not a multiple of 4", p.Cout);
   const long total = (long)p.N * p.Hout * p.Wout * (p.Cout / 4);
   long blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  out->fn = dtype == UDP_F32 ? reinterpret_cast<const void*>(kf) : reinterpret_cast<const void*>(kb);
+  out->fn = dtype == UDP_F32 ? reinterpret_cast<const void*>(kf)
+                             : dtype == UDP_F16X2 ? reinterpret_cast<const void*>(kh) : reinterpret_cast<const void*>(kb);
   out->grid = dim3((unsigned)blocks);
   out->block = dim3(256);
   out->lds = 0;
@@ -1541,18 +1666,19 @@ static int describe_elementwise(const ConvParams& p, int dtype, KF kf, KB kb, La
 }
 
 int describe_maxpool(const ConvParams& p, int dtype, Launch* out) {
-  return describe_elementwise(p, dtype, &maxpool3_kernel<float>, &maxpool3_kernel<__bf16>, out);
+  return describe_elementwise(p, dtype, &maxpool3_kernel<float>, &maxpool3_kernel<__bf16>, &maxpool3_kernel<H2>, out);
 }
 
 int describe_bilinear(const ConvParams& p, int dtype, Launch* out) {
-  return describe_elementwise(p, dtype, &bilinear_ac_kernel<float>, &bilinear_ac_kernel<__bf16>, out);
+  return describe_elementwise(p, dtype, &bilinear_ac_kernel<float>, &bilinear_ac_kernel<__bf16>, &bilinear_ac_kernel<H2>, out);
 }
 
 int describe_stem7(const ConvParams& p, int dtype, Launch* out) {
   if (p.Cout != 64) return fail(UDP_ERR_UNSUPPORTED, "7x7 stem expects 64 output channels, got %d", p.Cout);
   const long total = (long)p.N * p.Hout * p.Wout;
-  out->fn = dtype == UDP_F32 ? reinterpret_cast<const void*>(&stem7_conv_kernel<float>)
-                             : reinterpret_cast<const void*>(&stem7_conv_kernel<__bf16>);
+  out->fn = dtype == UDP_F32     ? reinterpret_cast<const void*>(&stem7_conv_kernel<float>)
+            : dtype == UDP_F16X2 ? reinterpret_cast<const void*>(&stem7_conv_kernel<H2>)
+                                 : reinterpret_cast<const void*>(&stem7_conv_kernel<__bf16>);
   out->grid = dim3((unsigned)((total + 63) / 64));
   out->block = dim3(256);
   out->lds = (147 * 64 + 64) * sizeof(float);

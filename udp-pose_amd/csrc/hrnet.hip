@@ -51,7 +51,7 @@ struct udp_hrnet {
   hipEvent_t ev_fork = nullptr, ev_join[UDP_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
 };
 
-static size_t esize(int dtype) { return dtype == UDP_F32 ? 4 : 2; }
+static size_t esize(int dtype) { return dtype == UDP_BF16 ? 2 : 4; }   // bytes per stored element (F16X2: hi + lo)
 
 static int validate_op(const udp_hrnet* h, const udp_conv_op& o, int idx) {
   const int nb = (int)h->buf_elems.size();
@@ -159,7 +159,7 @@ extern "C" int udp_hrnet_create(const udp_conv_op* ops, int n_ops, const int64_t
                                 int out_channels, udp_hrnet** out) {
   if (!ops || n_ops <= 0 || !buf_elems || n_bufs <= 0 || !weights_dev || !out)
     return fail(UDP_ERR_ARG, "udp_hrnet_create: null/empty argument");
-  if (dtype != UDP_F32 && dtype != UDP_BF16) return fail(UDP_ERR_ARG, "udp_hrnet_create: dtype %d", dtype);
+  if (dtype != UDP_F32 && dtype != UDP_BF16 && dtype != UDP_F16X2) return fail(UDP_ERR_ARG, "udp_hrnet_create: dtype %d", dtype);
   if (in_h <= 0 || in_w <= 0 || (in_h % 32) || (in_w % 32))
     return fail(UDP_ERR_UNSUPPORTED, "udp_hrnet_create: input %dx%d must be a multiple of 32", in_h, in_w);
   if (reinterpret_cast<uintptr_t>(weights_dev) & 15) return fail(UDP_ERR_ARG, "udp_hrnet_create: weights not 16-byte aligned");
@@ -528,7 +528,7 @@ extern "C" int udp_conv2d_fused(const udp_conv_op* o, int dtype, int n, const vo
                                 const float* bias, const void* res, const void* up0, const void* up1,
                                 const void* up2, void* out, void* stream) {
   if (!o || !in || !out) return fail(UDP_ERR_ARG, "udp_conv2d_fused: null pointer");
-  if (dtype != UDP_F32 && dtype != UDP_BF16) return fail(UDP_ERR_ARG, "udp_conv2d_fused: dtype %d", dtype);
+  if (dtype != UDP_F32 && dtype != UDP_BF16 && dtype != UDP_F16X2) return fail(UDP_ERR_ARG, "udp_conv2d_fused: dtype %d", dtype);
   if (n <= 0) return fail(UDP_ERR_ARG, "udp_conv2d_fused: n=%d", n);
   if (o->kind != UDP_OP_CONV && o->kind != UDP_OP_FUSE) return fail(UDP_ERR_ARG, "udp_conv2d_fused: kind %d", o->kind);
   if (o->kind == UDP_OP_CONV && (!weights || !bias)) return fail(UDP_ERR_ARG, "udp_conv2d_fused: conv needs weights and bias");

@@ -226,6 +226,7 @@ int describe_psa(const ConvParams& p, int dtype, int kind, Launch* out) {
   out->block = dim3(256);
   out->p = p;
   out->lds = 0;
+  if (dtype != UDP_F32 && dtype != UDP_BF16) return fail(UDP_ERR_UNSUPPORTED, "polarized self-attention ops: fp32 or bf16 storage only");
   const bool f = dtype == UDP_F32;
   switch (kind) {
     case UDP_OP_PSA_POOL: {

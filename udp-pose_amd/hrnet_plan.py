@@ -43,12 +43,36 @@ def _round_up(x, m):
     return (x + m - 1) // m * m
 
 
+DTYPES = ("f32", "bf16", "f16x2")
+F16X2_LO_SCALE = 2048.0          # csrc/conv.hip kLoScale
+
+
+def encode_weights(wp, dtype):
+    """[taps][cout_pad][cin] fp32 -> bytes in the storage dtype.  f16x2: rows of [cin hi][cin lo] fp16 with
+    w ~= hi + lo * 2^-11 (include/udp_pose_hip.h, UDP_F16X2); a folded weight beyond fp16's range is refused."""
+    if dtype == "bf16":
+        return wp.to(torch.bfloat16).contiguous().view(torch.uint8).numpy().tobytes()
+    if dtype == "f16x2":
+        if wp.numel() and float(wp.abs().max()) >= 32768.0:
+            raise ValueError("f16x2 storage: a BatchNorm-folded weight of magnitude %g exceeds the fp16 range"
+                             % float(wp.abs().max()))
+        hi = wp.to(torch.float16)
+        lo = ((wp - hi.to(torch.float32)) * F16X2_LO_SCALE).to(torch.float16)
+        return torch.stack([hi, lo], dim=2).contiguous().view(torch.uint8).numpy().tobytes()
+    return wp.contiguous().numpy().tobytes()
+
+
+def storage_bytes(dtype):
+    """Bytes per stored activation / weight element."""
+    return 2 if dtype == "bf16" else 4
+
+
 class HRNetProgram:
     """The compiled program: ops (ctypes array), buffer sizes, packed weights."""
 
     def __init__(self, state_dict, extra, in_h, in_w, dtype="f32"):
-        if dtype not in ("f32", "bf16"):
-            raise ValueError("dtype must be 'f32' or 'bf16'")
+        if dtype not in DTYPES:
+            raise ValueError("dtype must be one of %s" % (DTYPES,))
         if in_h % 32 or in_w % 32:
             raise ValueError("input %dx%d must be a multiple of 32" % (in_h, in_w))
         self.sd = {k[7:] if k.startswith("module.") else k: v for k, v in state_dict.items()}
@@ -93,10 +117,7 @@ class HRNetProgram:
         cout_pad = _round_up(cout, 32)
         wp = torch.zeros(kh * kw, cout_pad, cin, dtype=torch.float32)
         wp[:, :cout] = w.permute(2, 3, 0, 1).reshape(kh * kw, cout, cin)
-        if self.dtype == "bf16":
-            wbytes = wp.to(torch.bfloat16).contiguous().view(torch.uint8).numpy().tobytes()
-        else:
-            wbytes = wp.contiguous().numpy().tobytes()
+        wbytes = encode_weights(wp, self.dtype)
         bp = torch.zeros(cout_pad, dtype=torch.float32)
         bp[:cout] = b
         return self._put(wbytes), self._put(bp.numpy().tobytes()), cout, cin, kh, cout_pad
@@ -163,7 +184,9 @@ class HRNetProgram:
         if block.numel() != want:
             raise ValueError("%s: PSA parameter shapes do not match planes=%d" % (p, C))
         w_off = self._put(block.numpy().tobytes())
-        f = 4 // (2 if self.dtype == "bf16" else 4)                      # fp32 side rows, counted in dtype elements
+        if self.dtype == "f16x2":
+            raise ValueError("pose_hrnet_psa: the attention kernels run on fp32 or bf16 storage only")
+        f = 4 // storage_bytes(self.dtype)                               # fp32 side rows, counted in dtype elements
         base = dict(ks=1, stride=1, relu=0, cout_pad=_round_up(C, 32), hin=x.h, win=x.w, hout=x.h, wout=x.w,
                     res=None, ups=[], w_off=w_off, b_off=0)
         pooled = self._new(2 * C * f, 1, 1)

@@ -12,7 +12,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .hrnet_plan import HRNetProgram
+from .hrnet_plan import HRNetProgram, storage_bytes
 from .synth import hrnet_param_shapes
 
 
@@ -100,7 +100,7 @@ class PoseHighResolutionNetHip:
         bufs = (C.c_int64 * len(prog.buf_elems))(*prog.buf_elems)
         handle = C.c_void_p()
         _lib.check(_lib.lib().udp_hrnet_create(ops, len(ops), bufs, len(prog.buf_elems), _lib.ptr(blob),
-                                               blob.numel(), _lib.UDP_BF16 if self.dtype == "bf16" else _lib.UDP_F32,
+                                               blob.numel(), _lib.DTYPES[self.dtype],
                                                h, w, prog.out_channels, C.byref(handle)))
         self._compiled[(h, w)] = (handle, blob, prog)
         return self._compiled[(h, w)]
@@ -146,7 +146,7 @@ class PoseHighResolutionNetHip:
         handle, _, prog = self._compiled.get((h, w)) or self._compile(h, w)
         # one launch addresses a tensor with 32-bit byte offsets: split batches whose largest activation
         # ([2N, H/2, W/2, 64]) would pass 2 GiB
-        cap = max(1, (2 ** 31 - 1) // (max(t.elems for t in prog._tensors) * (2 if self.dtype == "bf16" else 4)
+        cap = max(1, (2 ** 31 - 1) // (max(t.elems for t in prog._tensors) * storage_bytes(self.dtype)
                                       * (2 if flip_test else 1)))
         cap = min(cap, self.max_images_per_launch or cap)
         if n > cap:

@@ -15,7 +15,7 @@ zero bias, ReLU).  The ``a + b`` that precedes most 3x3 convs is one element-wis
 import torch
 
 from . import _lib
-from .hrnet_plan import HRNetProgram, _round_up
+from .hrnet_plan import HRNetProgram, _round_up, encode_weights
 
 
 class RSNProgram(HRNetProgram):
@@ -50,10 +50,7 @@ class RSNProgram(HRNetProgram):
         wp[:, oi[:, None], ii[None, :]] = w.permute(2, 3, 0, 1).reshape(kh * kw, cout, cin)
         bp = torch.zeros(cout_pad, dtype=torch.float32)
         bp[oi] = b
-        if self.dtype == "bf16":
-            wbytes = wp.to(torch.bfloat16).contiguous().view(torch.uint8).numpy().tobytes()
-        else:
-            wbytes = wp.contiguous().numpy().tobytes()
+        wbytes = encode_weights(wp, self.dtype)
         return self._put(wbytes), self._put(bp.numpy().tobytes()), cout_t, cin_t, kh, cout_pad
 
     # ---- emission ------------------------------------------------------------------------------
