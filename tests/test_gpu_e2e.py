@@ -352,7 +352,8 @@ def test_fused_basic_block_equals_the_two_conv_launches(h, w, monkeypatch):
     assert e_f < 1.15 * e_u + 1e-4, (e_f, e_u)
 
 
-def test_merged_branch_launches_equal_separate_launches(monkeypatch):
+@pytest.mark.parametrize("dtype", ["bf16", "f16x2"])
+def test_merged_branch_launches_equal_separate_launches(monkeypatch, dtype):
     """bf16 graph mode: the same-depth convs of different branches run as ONE conv_mfma_multi launch
     (hrnet.hip build_graph).  Per output element the accumulation order does not depend on the tile
     choice, so the result equals the ungrouped program bit for bit; eager mode (per-op launches) too."""
@@ -366,7 +367,7 @@ def test_merged_branch_launches_equal_separate_launches(monkeypatch):
             monkeypatch.setenv("UDP_POSE_NO_GROUPS", "1")
         else:
             monkeypatch.delenv("UDP_POSE_NO_GROUPS", raising=False)
-        net = MODELS["pose_hrnet"](_cfg(extra, 17, "gaussian"), is_train=False, dtype="bf16").load_state_dict(sd).to("cuda")
+        net = MODELS["pose_hrnet"](_cfg(extra, 17, "gaussian"), is_train=False, dtype=dtype).load_state_dict(sd).to("cuda")
         net.use_graph = mode != "eager"
         groups = [o.group for o in net.program(128, 96).ops_array()]
         assert (max(groups) > 0) == (mode != "plain")
@@ -377,7 +378,7 @@ def test_merged_branch_launches_equal_separate_launches(monkeypatch):
     torch.testing.assert_close(outs["eager"], outs["plain"], rtol=0, atol=0)
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+@pytest.mark.parametrize("dtype", ["bf16", "f16x2", "f32"])
 def test_each_image_is_independent_of_its_batch(dtype):
     """Size-independent property: an image's heat-maps do not depend on which batch it is in (ragged tiles,
     several-images-per-tile kernels, merged launches, fused blocks, flip-test row order): batch of 5 vs the

@@ -13,7 +13,7 @@ def main():
     d = sys.argv[1]
     dtype = sys.argv[2] if len(sys.argv) > 2 else "bf16"
     top = int(sys.argv[3]) if len(sys.argv) > 3 else 8
-    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    f = (glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"))[0]
     per = collections.defaultdict(dict)
     for r in csv.DictReader(open(f)):
         if any(k in r["Kernel_Name"] for k in ("conv_mfma_kernel", "stem_conv_kernel", "fuse_sum_kernel")):

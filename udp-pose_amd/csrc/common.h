@@ -56,6 +56,7 @@ struct ConvParams {
   int relu;
   int out_nchw_f32;      // epilogue writes NCHW fp32 (network output) instead of NHWC T
   int flip_from;         // stem only: images >= flip_from read image (n - flip_from) mirrored in x
+  int sbuf;              // conv_mfma_kernel: one stage buffer instead of two (set by conv_choose_tile)
 };
 
 // Kernel argument of conv_mfma_multi: up to 4 independent convs in one launch (flat block index ->

@@ -528,12 +528,16 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int ti
   for (int c = 0; c < nchunks; ++c) {
     // chunk c has landed (explicit wait: the compiler is not obliged to track LDS-DMA) and every
     // wave is done with chunk c-1
+    if (p.sbuf && c > 0) {   // one stage buffer (two workgroups per CU hide each other's DMA): refill it once all waves left chunk c-1
+      __syncthreads();
+      stage(c, smem);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (c == 0) UDP_STAMP(3);
     __syncthreads();
     if (c == 0) UDP_STAMP(4);
-    if (c + 1 < nchunks) stage(c + 1, smem + ((c + 1) & 1) * stage_bytes);
-    const unsigned char* sb = smem + (c & 1) * stage_bytes;
+    if (!p.sbuf && c + 1 < nchunks) stage(c + 1, smem + ((c + 1) & 1) * stage_bytes);
+    const unsigned char* sb = p.sbuf ? smem : smem + (c & 1) * stage_bytes;
     if constexpr (PL == 2)
       mfma_chunk_h2<KS, NB, MBW>(acc, accx, sb, sb + PL * in_bytes + li * ROWB, in_bytes, W_BYTES, prow, IW, kg, wswz);
     else
@@ -1303,7 +1307,11 @@ size_t conv_choose_tile(ConvParams& p, int ks, int stride, int dtype, int* nb_ou
   const int kMaxM = (int)knob("UDP_POSE_MAXM", 256);
   const int ck = dtype == UDP_F32 ? 16 : 32;
   const int planes = dtype == UDP_F16X2 ? 2 : 1;
-  const int nstage = ceil_div(p.Cin, ck) > 1 ? 2 : 1;
+  // split-fp16 tiles are twice the bytes: K-deep convs keep ONE stage buffer so that two workgroups fit a CU
+  // (UDP_POSE_H2_DBUF=1: double-buffered, one workgroup of up to 156 KB per CU)
+  static const bool h2_dbuf = getenv("UDP_POSE_H2_DBUF") != nullptr;
+  p.sbuf = planes == 2 && !h2_dbuf;
+  const int nstage = ceil_div(p.Cin, ck) > 1 && !p.sbuf ? 2 : 1;
   int TW = p.Wout;
   while (TW > 64) TW = (TW + 1) / 2;
   int maxR = kMaxM / TW;
@@ -1546,8 +1554,10 @@ int describe_conv(ConvParams p, int dtype, int ks, int stride, Launch* out) {
 // into a conv_mfma_multi node): every member uses the instantiation <bf16, 3, 1, NB=2, MBW=4, 4 waves>.
 // Returns 1 when the conv does not qualify (the caller falls back to describe_conv).
 int describe_conv_grouped(ConvParams p, int dtype, int ks, int stride, Launch* out) {
-  if (dtype != UDP_BF16 || (ks != 3 && ks != 1) || stride != 1 || p.out_nchw_f32 || p.nup || p.Cin % 16 || p.Cout % 16 || p.CoutPad % 32) return 1;
-  if ((size_t)p.N * p.Hin * p.Win * p.in_pitch * 2 >= 0x7FFF0000u || (p.in_coff * 2) % 16 || (p.in_pitch * 2) % 16 ||
+  if ((dtype != UDP_BF16 && dtype != UDP_F16X2) || (ks != 3 && ks != 1) || stride != 1 || p.out_nchw_f32 || p.nup || p.Cin % 16 || p.Cout % 16 || p.CoutPad % 32) return 1;
+  const size_t pix_esz = dtype == UDP_BF16 ? 2 : 4;
+  if ((size_t)p.N * p.Hin * p.Win * p.in_pitch * pix_esz >= 0x7FFF0000u || (size_t)p.N * p.Hout * p.Wout * p.out_pitch * pix_esz >= 0x7FFF0000u ||
+      (p.in_coff * 2) % 16 || (p.in_pitch * 2) % 16 ||
       (p.out_coff * 2) % 16 || (p.out_pitch * 2) % 16 || (p.res && ((p.res_coff * 2) % 16 || (p.res_pitch * 2) % 16)) || p.N >= 2048)
     return 1;
   int nb = 2;
@@ -1559,34 +1569,46 @@ int describe_conv_grouped(ConvParams p, int dtype, int ks, int stride, Launch* o
   const int mbw = ceil_div(ceil_div(p.G * p.R * p.TW, 16), 4);
   const bool m3 = mbw <= 3 && getenv("UDP_POSE_MULTI_MBW4") == nullptr;
   int rc;
-  if (ks == 3)
+  if (dtype == UDP_F16X2) {
+    if (ks == 3)
+      rc = m3 ? describe_one<H2, 3, 1, 2, 3, false, 4>(p, lds, out) : describe_one<H2, 3, 1, 2, 4, false, 4>(p, lds, out);
+    else
+      rc = m3 ? describe_one<H2, 1, 1, 2, 3, false, 4>(p, lds, out) : describe_one<H2, 1, 1, 2, 4, false, 4>(p, lds, out);
+  } else if (ks == 3) {
     rc = m3 ? describe_one<__bf16, 3, 1, 2, 3, false, 4>(p, lds, out) : describe_one<__bf16, 3, 1, 2, 4, false, 4>(p, lds, out);
-  else
+  } else {
     rc = m3 ? describe_one<__bf16, 1, 1, 2, 3, false, 4>(p, lds, out) : describe_one<__bf16, 1, 1, 2, 4, false, 4>(p, lds, out);
+  }
   if (rc) return rc;
-  out->groupable = ks * 10 + (m3 ? 3 : 4);      // kernel size, pixel blocks per wave of the instantiation that can run it
+  // storage type (0 bf16, 1 split fp16), kernel size, pixel blocks per wave of the instantiation that can run it
+  out->groupable = (dtype == UDP_F16X2 ? 100 : 0) + ks * 10 + (m3 ? 3 : 4);
   return UDP_OK;
 }
 
 // Kernel + attribute for a merged launch of `n` groupable convs; fills the kernel argument.
 int describe_multi(const Launch* members, int n, ConvMulti* m, Launch* out) {
   static bool attr_set = false;
-  const void* kerns[4] = {reinterpret_cast<const void*>(&conv_mfma_multi<__bf16, 3, 1, 2, 3, 4>),
+  const void* kerns[8] = {reinterpret_cast<const void*>(&conv_mfma_multi<__bf16, 3, 1, 2, 3, 4>),
                           reinterpret_cast<const void*>(&conv_mfma_multi<__bf16, 3, 1, 2, 4, 4>),
                           reinterpret_cast<const void*>(&conv_mfma_multi<__bf16, 1, 1, 2, 3, 4>),
-                          reinterpret_cast<const void*>(&conv_mfma_multi<__bf16, 1, 1, 2, 4, 4>)};
+                          reinterpret_cast<const void*>(&conv_mfma_multi<__bf16, 1, 1, 2, 4, 4>),
+                          reinterpret_cast<const void*>(&conv_mfma_multi<H2, 3, 1, 2, 3, 4>),
+                          reinterpret_cast<const void*>(&conv_mfma_multi<H2, 3, 1, 2, 4, 4>),
+                          reinterpret_cast<const void*>(&conv_mfma_multi<H2, 1, 1, 2, 3, 4>),
+                          reinterpret_cast<const void*>(&conv_mfma_multi<H2, 1, 1, 2, 4, 4>)};
   if (!attr_set) {
     for (const void* k : kerns) UDP_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   if (n < 2 || n > 4) return fail(UDP_ERR_ARG, "describe_multi: %d members", n);
-  const int ks = members[0].groupable / 10;
+  const int h2 = members[0].groupable / 100;
+  const int ks = members[0].groupable / 10 % 10;
   int mbw = 3;
   for (int j = 0; j < n; ++j) {
-    if (members[j].groupable / 10 != ks) return fail(UDP_ERR_ARG, "describe_multi: members of different kernel sizes");
+    if (members[j].groupable / 10 != members[0].groupable / 10) return fail(UDP_ERR_ARG, "describe_multi: members of different kernel sizes / storage types");
     if (members[j].groupable % 10 > mbw) mbw = members[j].groupable % 10;
   }
-  const void* kern = kerns[(ks == 3 ? 0 : 2) + (mbw == 3 ? 0 : 1)];
+  const void* kern = kerns[4 * h2 + (ks == 3 ? 0 : 2) + (mbw == 3 ? 0 : 1)];
   memset(m, 0, sizeof(*m));
   unsigned total = 0, lds = 0;
   for (int j = 0; j < n; ++j) {

@@ -80,7 +80,7 @@ class HRNetProgram:
         self.dtype = dtype
         self.in_h, self.in_w = in_h, in_w
         self.fuse_blocks = os.environ.get("UDP_POSE_NO_BLOCK_FUSION") is None
-        self.group_convs = dtype == "bf16" and os.environ.get("UDP_POSE_NO_GROUPS") is None
+        self.group_convs = dtype in ("bf16", "f16x2") and os.environ.get("UDP_POSE_NO_GROUPS") is None
         self._groups = 0
         self._tensors = []
         self._ops = []          # dicts with _T references
