@@ -25,14 +25,19 @@ def main():
     cin, cout, h, w, ks, st, n = [int(x) for x in (a[:7] if len(a) >= 7 else (32, 32, 64, 48, 3, 1, 128))]
     dtype = a[7] if len(a) > 7 else "bf16"
     tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    h2 = dtype == "f16x2"
+    if h2:
+        tdt = torch.float32       # 4 bytes per element; the hi/lo bit patterns are filled below
     lib = _lib.lib()
     lib.udp_debug_set_stamps.argtypes = [C.c_void_p]
     pad = ks // 2
     ho, wo = (h + 2 * pad - ks) // st + 1, (w + 2 * pad - ks) // st + 1
-    x = torch.randn(n, h, w, cin, device="cuda").to(tdt)
-    wt = (torch.randn(ks * ks, (cout + 31) // 32 * 32, cin, device="cuda") * 0.05).to(tdt)
+    from udp_pose_amd import f16x2
+    enc = (lambda t: f16x2.encode(t)) if h2 else (lambda t: t.to(tdt))
+    x = enc(torch.randn(n, h, w, cin, device="cuda"))
+    wt = enc(torch.randn(ks * ks, (cout + 31) // 32 * 32, cin, device="cuda") * 0.05)
     b = torch.zeros((cout + 31) // 32 * 32, device="cuda")
-    res = torch.randn(n, ho, wo, cout, device="cuda").to(tdt)
+    res = enc(torch.randn(n, ho, wo, cout, device="cuda"))
     out = torch.empty(n, ho, wo, cout, device="cuda", dtype=tdt)
     op = _lib.ConvOp()
     op.kind, op.ks, op.stride, op.relu = _lib.UDP_OP_CONV, ks, st, 1
@@ -42,7 +47,7 @@ def main():
     stamps = torch.zeros(nslots, dtype=torch.int64, device="cuda")
 
     def run():
-        _lib.check(lib.udp_conv2d_fused(C.byref(op), _lib.UDP_BF16 if dtype == "bf16" else _lib.UDP_F32, n, _lib.ptr(x),
+        _lib.check(lib.udp_conv2d_fused(C.byref(op), _lib.DTYPES[dtype], n, _lib.ptr(x),
                                         _lib.ptr(wt), _lib.ptr(b), _lib.ptr(res), None, None, None, _lib.ptr(out),
                                         _lib.stream_ptr()))
     for _ in range(3):

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libudp_pose_hip.so")
+LIB_PATH = os.environ.get("UDP_POSE_LIB") or os.path.join(_HERE, "libudp_pose_hip.so")   # UDP_POSE_LIB: diagnostic builds
 
 UDP_OK = 0
 UDP_F32, UDP_BF16, UDP_F16X2 = 0, 1, 2

@@ -43,6 +43,9 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 // end; lo*lo ~ 2^-22 is dropped), i.e. fp32-grade results on the 2.5 PF fp16 matrix pipe instead of the
 // 157 TF fp32 one.  Memory layout: per pixel (or weight row) the C hi values, then the C lo values.
 struct H2 {};
+#ifndef UDP_WS_DBG
+#define UDP_WS_DBG 0   // ablation bits for diagnostic builds (tools/ablate_ws.sh): 1 no A prefetch, 2 no B reads, 4 no DMA after chunk 0
+#endif
 constexpr float kLoScale = 2048.f, kLoInv = 1.f / 2048.f;
 
 constexpr int ROWB = 64;   // LDS row: one pixel's (or one weight row's) 64-byte channel chunk
@@ -606,6 +609,287 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int ti
 template <typename T, int KS, int STRIDE, int NB, int MBW, bool NCHW, int NW>
 __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(const ConvParams p) {
   conv_mfma_body<T, KS, STRIDE, NB, MBW, NCHW, NW>(p, blockIdx.x, blockIdx.y);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight-stationary form for split-fp16 convs ("ws"): the MFMA A operand (weights) never passes through
+// LDS.  A wave owns one pair of 16-cout blocks and keeps that pair's fragments of the current tap row
+// (KS taps x 2 blocks x hi/lo) in registers -- loaded straight from global memory (L2-resident), one tap
+// row ahead -- and sweeps PB pixel blocks under them; LDS holds only the input halo tile (hi + lo image,
+// double-buffered over the K chunks).  Against conv_mfma_kernel<H2> (which stages 9*BN weight rows per
+// chunk next to the tile) this halves the LDS-DMA instructions, leaves LDS room for two workgroups per CU
+// at any K depth, drops the LDS reads per MFMA from 10/18 to 2/6, and a staged input tile serves 4 cout
+// pairs (128 channels) instead of one.
+//   workgroup = 4 waves = CP cout pairs x PG = 4/CP pixel groups; wave (cp, pg) computes pixel blocks
+//   pg*PB .. pg*PB+PB-1 of the tile (M <= 16*PB*PG pixels) x couts (blockIdx.y*CP + cp)*32 .. +31.
+// ---------------------------------------------------------------------------------------------
+template <int KS, int STRIDE, int PB, int CP, bool NCHW>
+__global__ __launch_bounds__(256, 2) void conv_ws_h2_kernel(const ConvParams p) {
+  using T = H2;
+  constexpr int CK = 32, ESZ = 2, NB = 2, NW = 4;
+  constexpr int PAD = KS / 2, TAPS = KS * KS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  UDP_STAMP(0);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15;
+  const int kg = lane >> 4;
+  const int cp = wave % CP, pg = wave / CP;          // 4 waves = CP cout pairs x 4/CP pixel groups
+
+  int t = blockIdx.x;   // wave-uniform tile decode
+  const int tx = t % p.tiles_x;
+  t /= p.tiles_x;
+  const int ty = t % p.tiles_y;
+  const int n0 = (t / p.tiles_y) * p.G;
+  const int y0 = ty * p.R;
+  const int x0 = tx * p.TW;
+
+  const int IH = p.IH, IW = p.IW;
+  const int npix_in = p.G * IH * IW;
+  const int in_groups = (npix_in + 15) >> 4;
+  const int in_bytes = in_groups * 16 * ROWB;
+  const int stage_bytes = 2 * in_bytes;             // [hi image][lo image]
+  const int nchunks = (p.Cin + CK - 1) / CK;
+  const bool ragged = (p.Cin % CK) != 0;
+  const int RT = p.R * p.TW;
+  const int M = p.G * RT;
+  const unsigned cinb = (unsigned)p.Cin * ESZ * 2;
+  const unsigned inpb = (unsigned)p.in_pitch * ESZ * 2;
+  const unsigned outpb = (unsigned)p.out_pitch * ESZ * 2, respb = (unsigned)p.res_pitch * ESZ * 2;
+  const unsigned w_lo = (unsigned)p.Cin * ESZ, in_lo = (unsigned)p.in_pitch * ESZ;
+  const unsigned out_lo = (unsigned)p.out_pitch * ESZ, res_lo = (unsigned)p.res_pitch * ESZ;
+
+  const unsigned out_pix = (unsigned)p.N * p.Hout * p.Wout;
+  const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.in), 0, (unsigned)p.N * p.Hin * p.Win * inpb, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.wgt), 0, (unsigned)TAPS * p.CoutPad * cinb, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(
+      p.out, 0, NCHW ? out_pix * p.Cout * 4 : out_pix * outpb, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(p.res), 0, p.res ? out_pix * respb : 0, 0x00020000);
+
+  // ---- per-lane DMA offsets of the input halo tile (chunk 0); masked rows -> kOobOff -> zeros
+  const int srow = lane >> 2, spart = lane & 3;
+  const int gy0 = y0 * STRIDE - PAD, gx0 = x0 * STRIDE - PAD;
+  unsigned src_off[MAXG];
+#pragma unroll
+  for (int i = 0; i < MAXG; ++i) {
+    unsigned off = kOobOff;
+    if ((wave + NW * i) * 16 < npix_in) {   // wave-uniform
+      const int row = (wave + NW * i) * 16 + srow;
+      const int tmp = fdiv20(row, p.mIW);
+      const int ix = row - (int)__umul24(tmp, IW);
+      const int g = fdiv20(tmp, p.mIH);
+      const int iy = tmp - (int)__umul24(g, IH);
+      const int n = n0 + g, gy = gy0 + iy, gx = gx0 + ix;
+      const bool ok = row < npix_in && n < p.N && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win;
+      const unsigned pix = __umul24(__umul24(n, p.Hin) + gy, p.Win) + gx;
+      off = ok ? pix * inpb + p.in_coff * ESZ + ((spart ^ swz<T>(row)) << 4) : kOobOff;
+    }
+    src_off[i] = off;
+  }
+  auto stage = [&](int c, unsigned char* sb) __attribute__((always_inline)) {
+    const unsigned coff = (unsigned)c * (CK * ESZ);
+    const bool cut = ragged && c == nchunks - 1;
+    const int parts_left = (p.Cin - c * CK) / 8;
+#pragma unroll
+    for (int i = 0; i < MAXG; ++i) {
+      const int gidx = wave + NW * i;
+      if (gidx < in_groups) {
+        unsigned off = src_off[i] + coff;
+        if (cut && (spart ^ swz<T>(gidx * 16 + srow)) >= parts_left) off = kOobOff;
+        blds16(r_in, off, sb + gidx * (16 * ROWB));
+        blds16(r_in, off + in_lo, sb + in_bytes + gidx * (16 * ROWB));
+      }
+    }
+  };
+
+  // ---- the lane's PB output pixels
+  int prow[PB], opix[PB], ocrd[PB];
+  const int cwave = (blockIdx.y * CP + cp) * 32;   // first cout of the wave's pair of blocks
+  const int cbase = cwave + 8 * kg;                // the lane's 8 consecutive output channels
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int m0 = (pg * PB + i) * 16 + li;
+    const int m = m0 < M ? m0 : M - 1;
+    const int g = fdiv20(m, p.mRT);
+    const int rem = m - (int)__umul24(g, RT);
+    const int r = fdiv20(rem, p.mTW);
+    const int x = rem - (int)__umul24(r, p.TW);
+    prow[i] = (int)__umul24(__umul24(g, IH) + r * STRIDE, IW) + x * STRIDE;
+    const int n = n0 + g, y = y0 + r, xo = x0 + x;
+    const bool ok = m0 < M && n < p.N && y < p.Hout && xo < p.Wout && (NCHW || cbase < p.Cout);
+    const unsigned pix = __umul24(__umul24(n, p.Hout) + y, p.Wout) + xo;
+    opix[i] = ok ? (int)pix : -1;
+    ocrd[i] = ok ? (y | (xo << 10) | (n << 20)) : -1;
+  }
+
+  // ---- weights: A-fragment row li of block nb is cout cwave + 8*(li>>2) + 4*nb + (li&3) (so that a lane ends
+  // up with 8 consecutive couts); its 8 K values are the lane's 16 bytes at kg*16 of the chunk's 64-byte row
+  unsigned wvoff[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) wvoff[nb] = (unsigned)(cwave + 8 * (li >> 2) + 4 * nb + (li & 3)) * cinb + kg * 16;
+  const unsigned tap_stride = (unsigned)p.CoutPad * cinb;
+  // A fragments of one tap (2 blocks x hi/lo = 16 registers) in a ring of three: the fragments of step s + 2
+  // stream in from L2 while step s feeds the MFMAs (step = one tap of one K chunk)
+  f16x8 ah[3][NB], al[3][NB];
+  const int nsteps = nchunks * TAPS;
+  auto load_a = [&](int s, f16x8 (&h)[NB], f16x8 (&l)[NB]) __attribute__((always_inline)) {
+    const int c = s / TAPS, tap = s - c * TAPS;
+    const bool dead = ragged && c == nchunks - 1 && kg >= (p.Cin - c * CK) / 8;
+    const unsigned soff = (unsigned)tap * tap_stride + (unsigned)c * (CK * ESZ);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const unsigned vo = dead ? kOobOff : wvoff[nb];
+      h[nb] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r_w, vo, soff, 0));
+      l[nb] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r_w, vo + w_lo, soff, 0));
+    }
+  };
+
+  f32x4 acc[PB][NB], accx[PB][NB];
+  {
+    f32x4 bias[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) bias[nb] = *reinterpret_cast<const f32x4*>(p.bias + cbase + 4 * nb);
+#pragma unroll
+    for (int i = 0; i < PB; ++i)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        acc[i][nb] = bias[nb];
+        accx[i][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+  }
+
+  UDP_STAMP(1);
+  stage(0, smem);
+  load_a(0, ah[0], al[0]);
+  load_a(nsteps > 1 ? 1 : 0, ah[1], al[1]);
+  if constexpr (!NCHW) {
+    if (p.res) {
+#pragma unroll
+      for (int i = 0; i < PB; ++i)
+        add_vec_buf<T, NB>(acc[i], r_res, opix[i] >= 0 ? (unsigned)opix[i] * respb + (p.res_coff + cbase) * ESZ : kOobOff, res_lo);
+    }
+  }
+
+  UDP_STAMP(2);
+  int c = 0, tap = 0;                     // chunk / tap of the current step
+  const unsigned char* sb = smem;
+  auto step = [&](auto BUFC, int s) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(BUFC)::value;
+    // the A loads go first: vector-memory operations complete in issue order, fragments queued behind the
+    // next chunk's DMA would wait for it
+    // (issued unconditionally -- past the end the last step's fragments are fetched again: a prefetch under a
+    // branch makes hipcc assume nothing newer is in flight and wait with vmcnt(0) at every use)
+#if !(UDP_WS_DBG & 1)
+    load_a(s + 2 < nsteps ? s + 2 : nsteps - 1, ah[(BUF + 2) % 3], al[(BUF + 2) % 3]);
+#endif
+    if (tap == 0) {
+      // chunk c's DMA has landed (vector-memory operations complete in issue order: all but the 2*NB A loads
+      // just issued, which may stay in flight)
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      if (s == 0) UDP_STAMP(3);
+      __syncthreads();                                    // ... for every wave; nobody reads the other stage any more
+      if (s == 0) UDP_STAMP(4);
+#if !(UDP_WS_DBG & 4)
+      if (c + 1 < nchunks) stage(c + 1, smem + ((c + 1) & 1) * stage_bytes);
+#endif
+      sb = smem + (c & 1) * stage_bytes;
+    }
+    const int tap_rows = KS == 1 ? 0 : (tap / KS) * IW + tap % KS;
+    // B fragments (hi, lo) in a ring of three: the LDS reads of block i + 2 are issued before the MFMAs of
+    // block i (one wave per SIMD has nothing else to cover the ~200-cycle LDS latency with)
+    f16x8 xh[3], xl[3];
+    auto load_b = [&](int i, f16x8& h, f16x8& l) __attribute__((always_inline)) {
+      const int row = prow[i] + tap_rows;
+      const unsigned char* q = sb + row * ROWB + ((kg ^ swz<T>(row)) << 4);
+      h = *reinterpret_cast<const f16x8*>(q);
+      l = *reinterpret_cast<const f16x8*>(q + in_bytes);
+    };
+    load_b(0, xh[0], xl[0]);
+    if (PB > 1) load_b(1, xh[1], xl[1]);
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+#if !(UDP_WS_DBG & 2)
+      if (i + 2 < PB) load_b(i + 2, xh[(i + 2) % 3], xl[(i + 2) % 3]);
+#endif
+      __builtin_amdgcn_sched_barrier(0);   // keep those LDS reads ahead of this block's MFMAs (hipcc sinks them otherwise)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[BUF][nb], xh[i % 3], acc[i][nb], 0, 0, 0);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) accx[i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[BUF][nb], xl[i % 3], accx[i][nb], 0, 0, 0);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) accx[i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[BUF][nb], xh[i % 3], accx[i][nb], 0, 0, 0);
+    }
+    if (++tap == TAPS) {
+      tap = 0;
+      ++c;
+    }
+  };
+  for (int s = 0; s < nsteps; s += 3) {
+    step(std::integral_constant<int, 0>{}, s);
+    if (s + 1 < nsteps) step(std::integral_constant<int, 1>{}, s + 1);
+    if (s + 2 < nsteps) step(std::integral_constant<int, 2>{}, s + 2);
+  }
+  UDP_STAMP(5);
+#pragma unroll
+  for (int i = 0; i < PB; ++i)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[i][nb] += accx[i][nb] * kLoInv;
+
+  // ---- epilogue: lane holds couts cbase .. cbase + 7 of pixel i
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    f32x4 v[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) v[nb] = acc[i][nb];
+    if constexpr (NCHW) {
+      const int crd = ocrd[i];
+      const int y = crd & 1023, xo = (crd >> 10) & 1023, n = crd >> 20;
+      const unsigned hw = __umul24(p.Hout, p.Wout);
+      const unsigned base = __umul24(__umul24(__umul24(n, p.Cout), p.Hout) + y, p.Wout) + xo;
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int cc = cbase + 4 * nb + q;
+          float f = v[nb][q];
+          if (p.relu) f = f > 0.f ? f : 0.f;
+          const unsigned off = (crd >= 0 && cc < p.Cout) ? (base + cc * hw) * 4u : kOobOff;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, f), r_out, off, 0, 0);
+        }
+    } else {
+      const unsigned ooff = opix[i] >= 0 ? (unsigned)opix[i] * outpb + (p.out_coff + cbase) * ESZ : kOobOff;
+      if (p.nup) {   // wave-uniform, rare (exchange-unit outputs only)
+        const int crd = ocrd[i];
+        const int y = crd & 1023, xo = (crd >> 10) & 1023, n = crd >> 20;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          if (u < p.nup) {
+            const int sh = p.up_shift[u];
+            const long up_pix = ((long)(n * (p.Hout >> sh) + (y >> sh)) * (p.Wout >> sh) + (xo >> sh));
+            if (crd >= 0)
+              add_vec<T, NB>(v, reinterpret_cast<const unsigned char*>(p.up[u]) + (up_pix * p.Cout * 2 + cbase) * ESZ, p.Cout * ESZ);
+          }
+        }
+      }
+      if (p.relu) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[nb][q] = v[nb][q] > 0.f ? v[nb][q] : 0.f;
+      }
+      store_vec_buf<T, NB>(r_out, ooff, out_lo, v);
+    }
+  }
+  UDP_STAMP(6);
+#ifdef UDP_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  UDP_STAMP(7);
+#endif
 }
 
 // Horizontal fusion: up to 4 independent convs (the same-depth convs of different HRNet branches, which
@@ -1518,6 +1802,117 @@ int describe_block(ConvParams p, int dtype, Launch* out) {
   return fail(UDP_ERR_UNSUPPORTED, "fused BasicBlock: no kernel for %d columns", p.Win);
 }
 
+// Weight-stationary split-fp16 conv (conv_ws_h2_kernel): tile choice + dispatch.  Returns 1 when the
+// shape does not qualify (the caller falls back to conv_mfma_kernel<H2>).
+template <int KS, int STRIDE, int PB, int CP, bool NCHW>
+static int describe_ws_one(const ConvParams& p, size_t lds, Launch* out) {
+  static bool attr_set = false;
+  const void* kern = reinterpret_cast<const void*>(&conv_ws_h2_kernel<KS, STRIDE, PB, CP, NCHW>);
+  if (!attr_set) {
+    UDP_HIP_CHECK(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  out->fn = kern;
+  out->grid = dim3(p.ntiles, p.CoutPad / (CP * 32));
+  out->block = dim3(256);
+  out->lds = (unsigned)lds;
+  out->p = p;
+  return UDP_OK;
+}
+template <int KS, int STRIDE, bool NCHW>
+static int describe_ws_pb(const ConvParams& p, int pb, int cp, size_t lds, Launch* out) {
+#define UDP_WS(B, C) \
+  if (pb == B && cp == C) return describe_ws_one<KS, STRIDE, B, C, NCHW>(p, lds, out);
+  UDP_WS(2, 1) UDP_WS(3, 1) UDP_WS(4, 1) UDP_WS(6, 1) UDP_WS(2, 2) UDP_WS(3, 2) UDP_WS(4, 2) UDP_WS(6, 2)
+  UDP_WS(2, 4) UDP_WS(3, 4) UDP_WS(4, 4) UDP_WS(6, 4)
+#undef UDP_WS
+  return 1;
+}
+struct WsTile {
+  int cp, pb, G, R, TW, wgs;
+  size_t lds;
+};
+// Tile of a (cout pairs per workgroup, pixel blocks per wave) candidate; false if it cannot be built.
+static bool ws_tile(const ConvParams& p, int ks, int stride, int cp, int pb, WsTile* t) {
+  const int pg = 4 / cp;
+  const int maxM = 16 * pb * pg;
+  int TW = p.Wout;
+  while (TW > 64 || TW > maxM) TW = (TW + 1) / 2;
+  int maxR = maxM / TW;
+  if (maxR > p.Hout) maxR = p.Hout;
+  int R = largest_divisor_leq(p.Hout, maxR);
+  if (R * 2 <= maxR) R = maxR;
+  int G = 1;
+  if (R == p.Hout && TW == p.Wout) {
+    G = maxM / (R * TW);
+    if (G > p.N) G = p.N;
+    if (G < 1) G = 1;
+  }
+  auto npix = [&](int g, int r) { return g * ((r - 1) * stride + ks) * ((TW - 1) * stride + ks); };
+  while (npix(G, R) > MAXG * 64 && G > 1) --G;
+  while (npix(G, R) > MAXG * 64 && R > 1) R = (R + 1) / 2;
+  if (npix(G, R) > MAXG * 64) return false;
+  const int nstage = ceil_div(p.Cin, 32) > 1 ? 2 : 1;
+  t->lds = (size_t)((npix(G, R) + 15) / 16) * 16 * ROWB * 2 * nstage;
+  if (t->lds > 160 * 1024) return false;
+  t->cp = cp;
+  t->pb = pb;
+  t->G = G;
+  t->R = R;
+  t->TW = TW;
+  t->wgs = ceil_div(p.N, G) * ceil_div(p.Hout, R) * ceil_div(p.Wout, TW) * (p.CoutPad / (cp * 32));
+  return true;
+}
+
+static int describe_conv_ws(ConvParams p, int ks, int stride, Launch* out) {
+  // Opt-in (UDP_POSE_WS=1) while it is slower than conv_mfma_kernel<H2> on most HRNet shapes: measured on
+  // MI355X its A-fragment loads (4 KiB per wave and tap from L2, half-used cache lines) cost ~25 % of the
+  // launch; see DESIGN.md "Weight-stationary experiment".
+  static const bool on = getenv("UDP_POSE_WS") != nullptr;
+  if (!on || stride != 1 || (ks != 3 && ks != 1) || p.out_nchw_f32) return 1;
+  auto knob = [](const char* name, long dflt) {
+    const char* v = getenv(name);
+    return v ? atol(v) : dflt;
+  };
+  const int pairs = p.CoutPad / 32;
+  const int force_cp = (int)knob("UDP_POSE_WS_CP", 0), force_pb = (int)knob("UDP_POSE_WS_PB", 0);
+  const long min_wgs = knob("UDP_POSE_WS_MINWGS", 512);        // two workgroups on each of the 256 CUs
+  // candidates from the fattest wave tile down: the first one that fills the chip wins, else the one with
+  // the most workgroups
+  WsTile best{}, t{};
+  bool have = false;
+  for (int pb : {6, 4, 3, 2}) {
+    for (int cp : {4, 2, 1}) {
+      if (pairs % cp || (force_cp && cp != force_cp) || (force_pb && pb != force_pb)) continue;
+      if (!ws_tile(p, ks, stride, cp, pb, &t)) continue;
+      const bool fills = t.wgs >= min_wgs, best_fills = have && best.wgs >= min_wgs;
+      if (!have || (!best_fills && (fills || t.wgs > best.wgs))) {
+        best = t;
+        have = true;
+      }
+    }
+  }
+  if (!have) return 1;
+  p.G = best.G;
+  p.R = best.R;
+  p.TW = best.TW;
+  p.IH = (p.R - 1) * stride + ks;
+  p.IW = (p.TW - 1) * stride + ks;
+  p.tiles_x = ceil_div(p.Wout, p.TW);
+  p.tiles_y = ceil_div(p.Hout, p.R);
+  auto magic = [](int d) { return (unsigned)(((1u << 20) + (unsigned)d - 1) / (unsigned)d); };
+  p.mIW = magic(p.IW);
+  p.mIH = magic(p.IH);
+  p.mRT = magic(p.R * p.TW);
+  p.mTW = magic(p.TW);
+  p.ntiles = ceil_div(p.N, p.G) * p.tiles_y * p.tiles_x;
+  if (getenv("UDP_POSE_DEBUG_TILES"))
+    fprintf(stderr, "ws conv k%d s%d %dx%d C%d->%d: G=%d R=%d TW=%d CP=%d PB=%d lds=%zu wgs=%d\n", ks, stride, p.Hout, p.Wout, p.Cin,
+            p.Cout, p.G, p.R, p.TW, best.cp, best.pb, best.lds, best.wgs);
+  if (ks == 3) return describe_ws_pb<3, 1, false>(p, best.pb, best.cp, best.lds, out);
+  return describe_ws_pb<1, 1, false>(p, best.pb, best.cp, best.lds, out);
+}
+
 // Fills `out` with the kernel, grid and arguments of one fused conv (tile choice included).
 int describe_conv(ConvParams p, int dtype, int ks, int stride, Launch* out) {
   if (p.Cin % 16 != 0) return fail(UDP_ERR_UNSUPPORTED, "conv Cin=%d is not a multiple of 16", p.Cin);
@@ -1533,6 +1928,10 @@ int describe_conv(ConvParams p, int dtype, int ks, int stride, Launch* out) {
   if (false ||
       p.N >= 2048)
     return fail(UDP_ERR_UNSUPPORTED, "conv tensor exceeds the 2 GiB the 32-bit buffer offsets cover; split the batch");
+  if (dtype == UDP_F16X2) {
+    const int rc = describe_conv_ws(p, ks, stride, out);
+    if (rc <= 0) return rc;
+  }
   int nb = 2;
   const size_t lds = conv_choose_tile(p, ks, stride, dtype, &nb);
   if (p.CoutPad % (nb * 16) != 0)
