@@ -171,3 +171,18 @@ def test_launch_groups_are_independent():
             assert o.kind == _lib.UDP_OP_CONV and o.ks == ops[idx[0]].ks and o.stride == 1 and o.n_up == 0
             reads = {o.in_buf, o.res_buf} - {_lib.UDP_BUF_NONE}
             assert not (reads & (set(outs) - {o.out_buf})), (g, i)
+
+
+def test_bench_gpus_n_launches_its_own_ranks():
+    """`bench.py --gpus 2` from a plain shell (no torch.distributed environment) starts two ranks of itself
+    before touching the GPU; in this GPU-less container both stop at the explicit "needs a GPU" exit and the
+    parent passes the failure on (RSN/exps/RSN18.coco/test.py:158 launches its ranks the same way)."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0
+        assert (r.stdout + r.stderr).count("bench.py needs a GPU") == 2
