@@ -76,11 +76,75 @@ def test_train_epoch_drives_the_trainer():
     sd = synth.synth_state_dict(EXTRA, 17, "gaussian", seed=32)
     loader = _loader(1, 4, "gaussian", 70) * 6                  # the same batch six times: the loss must fall
     tr = HRNetTrainer(cfg, sd, device="cuda", lr=1e-3)
-    first = ufn.train(cfg, loader[:1], tr, ufn.JointsMSELoss(), None, 0)
+    opt = ufn.Adam([], lr=1e-3)
+    first = ufn.train(cfg, loader[:1], tr, ufn.JointsMSELoss(), opt, 0)
     last = None
     for _ in range(3):
-        last = ufn.train(cfg, loader, tr, ufn.JointsMSELoss(), None, 1)
+        last = ufn.train(cfg, loader, tr, ufn.JointsMSELoss(), opt, 1)
     assert last < 0.8 * first and tr.step_count == 1 + 18
+
+
+def test_integration_md_training_snippet_runs_verbatim():
+    """The training sequence of INTEGRATION.md (= tools/train.py:91,116-125,164,183-196 with the import swaps):
+    MODELS[name](cfg, is_train=True) -> criterion -> get_optimizer -> train() -> validate() on the same object;
+    the weights validate() runs on are the trained ones; a scheduler's lr change reaches the step; unsupported
+    criteria / optimizers are refused, not ignored."""
+    from udp_pose_amd.config import default_config
+    from udp_pose_amd.model import MODELS
+    from udp_pose_amd.function import JointsMSELoss, get_optimizer, train, validate
+    cfg = default_config()
+    cfg.MODEL.NAME = "pose_hrnet"
+    cfg.MODEL.EXTRA = EXTRA
+    cfg.MODEL.NUM_JOINTS = 17
+    cfg.MODEL.TARGET_TYPE = "gaussian"
+    cfg.MODEL.INIT_WEIGHTS = True
+    cfg.MODEL.PRETRAINED = ""
+    cfg.TRAIN.LR = 1e-3
+    cfg.TRAIN.OPTIMIZER = "adam"
+    cfg.TEST.FLIP_TEST = True
+    cfg.TEST.POST_PROCESS = True
+    torch.manual_seed(5)
+    train_loader = _loader(1, 4, "gaussian", 70) * 4
+    valid_loader = _loader(2, 3, "gaussian", 71)
+    valid_dataset = _DS(6)
+
+    model = MODELS[cfg.MODEL.NAME](cfg, is_train=True)
+    model = model.cuda()
+    criterion = JointsMSELoss(use_target_weight=True)
+    optimizer = get_optimizer(cfg, model)
+    w0 = model.state_dict()["conv1.weight"].clone()
+    assert abs(float(w0.std()) - 1e-3) < 2e-4 and float(model.state_dict()["bn1.weight"].mean()) == 1.0   # init_weights
+    losses = []
+    for epoch in range(3):
+        losses.append(train(cfg, train_loader, model, criterion, optimizer, epoch, None, None, None))
+        all_preds, all_boxes, paths, val_loss = validate(cfg, valid_loader, valid_dataset, model, criterion, None, None, None)
+        assert np.isfinite(all_preds).all() and np.isfinite(val_loss)
+    assert losses[-1] < losses[0]
+    sd = model.state_dict()
+    assert not torch.equal(sd["conv1.weight"], w0)                      # validate() saw trained weights
+    assert set(sd) == set(synth.hrnet_param_shapes(EXTRA, 17, "gaussian"))
+    # the eval-mode forward runs the trained weights: same heat-maps as a fresh inference model loaded from them
+    x = valid_loader[0][0].cuda()
+    fresh = MODELS["pose_hrnet"](cfg, is_train=False).load_state_dict(sd).cuda().eval()
+    torch.testing.assert_close(model.eval()(x).clone(), fresh(x).clone(), rtol=0, atol=0)
+    # a scheduler's lr reaches the kernel: with lr = 0 the parameters stop moving
+    optimizer.param_groups[0]["lr"] = 0.0
+    before = model.parameters()[0].clone()
+    train(cfg, train_loader[:1], model, criterion, optimizer, 3, None, None, None)
+    assert torch.equal(before, model.parameters()[0])
+    # a real torch.optim.Adam over model.parameters() is accepted; SGD / weight decay / other criteria are refused
+    train(cfg, train_loader[:1], model, criterion, torch.optim.Adam(model.parameters(), lr=1e-4), 4, None, None, None)
+    for bad in (torch.optim.SGD(model.parameters(), lr=0.1), torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-4)):
+        with pytest.raises(NotImplementedError):
+            train(cfg, train_loader[:1], model, criterion, bad, 5, None, None, None)
+
+    class JointsOHKMMSELoss:
+        use_target_weight = True
+    with pytest.raises(NotImplementedError):
+        train(cfg, train_loader[:1], model, JointsOHKMMSELoss(), optimizer, 5, None, None, None)
+    cfg.TRAIN.OPTIMIZER = "sgd"
+    with pytest.raises(NotImplementedError):
+        get_optimizer(cfg, model)
 
 
 def test_accuracy_matches_reference_fixture(golden_dir):

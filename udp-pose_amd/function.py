@@ -3,9 +3,10 @@
 
 * ``JointsMSELoss`` / ``JointsMSELoss_offset`` (loss.py:15-39 / :41-76): callables returning the loss
   value(s) as device fp64 scalars (``udp_mse_loss``); ``.last_grad`` holds d loss / d output.
-* ``train(config, train_loader, model, criterion, optimizer, epoch, ...)``: ``model`` is a
-  ``train.HRNetTrainer`` (it owns parameters, Adam state and the backward); ``criterion`` / ``optimizer`` are
-  accepted for signature compatibility (the trainer runs the same criterion and Adam rule internally).
+* ``train(config, train_loader, model, criterion, optimizer, epoch, ...)``: ``model`` is what
+  ``MODELS[name](cfg, is_train=True)`` returned; its ``train.HRNetTrainer`` owns parameters, Adam moments and the
+  backward.  ``criterion`` and ``optimizer`` are honoured (use_target_weight; lr / betas / eps per batch) and
+  anything the kernels do not implement (another loss, SGD, weight decay) raises instead of being ignored.
 * ``validate(config, val_loader, val_dataset, model, criterion, ...)``: forward + mirrored forward in one
   launch sequence, ``udp_flip_fuse``, loss, ``get_final_preds``; fills ``all_preds`` / ``all_boxes`` exactly as
   :212-221 does and hands them to ``val_dataset.evaluate`` when the dataset has one.
@@ -104,15 +105,75 @@ def accuracy(output, target, hm_type="gaussian", thr=0.5):
     return acc, avg, cnt, pred
 
 
-def train(config, train_loader, model, criterion=None, optimizer=None, epoch=0, output_dir=None, tb_log_dir=None,
+def get_optimizer(cfg, model):
+    """lib/utils/utils.py:60-76.  TRAIN.OPTIMIZER 'adam' -> ``Adam(model.parameters(), lr=cfg.TRAIN.LR)``.  'sgd' is
+    refused: the training step implements the Adam rule only."""
+    name = str(_cfg(cfg, "TRAIN", "OPTIMIZER", default="adam")).lower()
+    if name != "adam":
+        raise NotImplementedError("TRAIN.OPTIMIZER=%r: the HIP training step implements Adam (utils.py:70-74) only" % name)
+    return Adam(model.parameters(), lr=float(_cfg(cfg, "TRAIN", "LR", default=1e-3)))
+
+
+class Adam:
+    """Stand-in for ``torch.optim.Adam(params, lr)`` with its defaults: holds the hyper-parameters in
+    ``param_groups`` (so ``MultiStepLR``-style schedulers can rewrite ``lr``); the moments live in the trainer and
+    the update itself is ``udp_adam_step``.  A real ``torch.optim.Adam`` over ``model.parameters()`` is accepted
+    by ``train`` too."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
+        self.param_groups = [dict(params=list(params), lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay,
+                                  amsgrad=amsgrad)]
+
+    def zero_grad(self):
+        pass                                               # every gradient is overwritten by the backward
+
+
+def _adam_hyper(optimizer):
+    """(lr, betas, eps) of the optimizer handed to train(); anything the Adam kernel does not implement is refused."""
+    if type(optimizer).__name__ != "Adam" or len(optimizer.param_groups) != 1:
+        raise NotImplementedError("train(): optimizer %s is not supported -- pass Adam over model.parameters() "
+                                  "(one parameter group)" % type(optimizer).__name__)
+    g = optimizer.param_groups[0]
+    if g.get("weight_decay", 0) or g.get("amsgrad", False) or g.get("maximize", False):
+        raise NotImplementedError("train(): Adam with weight_decay / amsgrad / maximize is not implemented")
+    return float(g["lr"]), tuple(float(b) for b in g["betas"]), float(g["eps"])
+
+
+def _check_criterion(criterion, target_type):
+    """The backward starts from the gradient of JointsMSELoss / JointsMSELoss_offset (loss.py:15-76); any other
+    criterion (e.g. JointsOHKMMSELoss) would silently train a different objective -> refused."""
+    name = type(criterion).__name__
+    want = "JointsMSELoss_offset" if target_type == "offset" else "JointsMSELoss"
+    if name != want:
+        raise NotImplementedError("train(): criterion %s is not supported with TARGET_TYPE=%s (expected %s)"
+                                  % (name, target_type, want))
+    return bool(getattr(criterion, "use_target_weight", True))
+
+
+def train(config, train_loader, model, criterion, optimizer, epoch=0, output_dir=None, tb_log_dir=None,
           writer_dict=None, world_size=1):
-    """function.py:27-111.  Returns the sample-weighted mean loss of the epoch (what ``losses.avg`` holds)."""
-    total, count = torch.zeros(2, dtype=torch.float64, device=model.device), 0
+    """function.py:27-111: ``model.train()``, then per batch forward -> criterion -> backward -> optimizer step.
+    ``model`` is what ``MODELS[name](cfg, is_train=True)`` returned (or a train.HRNetTrainer); ``criterion`` must be
+    JointsMSELoss / JointsMSELoss_offset and ``optimizer`` Adam over ``model.parameters()`` -- their
+    hyper-parameters (use_target_weight; lr, betas, eps, re-read every batch) are honoured, anything else raises.
+    Returns the sample-weighted mean loss of the epoch (what ``losses.avg`` holds)."""
+    from .train import HRNetTrainer
+    if isinstance(model, HRNetTrainer):
+        trainer = model
+    else:
+        model.train()
+        trainer = model.trainer()
+    use_tw = _check_criterion(criterion, trainer.target_type)
+    total, count = torch.zeros(2, dtype=torch.float64, device=trainer.device), 0
     for input, target, target_weight, meta in train_loader:
         n = input.shape[0]
-        loss = model.train_step(input.to(model.device, non_blocking=True).contiguous(),
-                                target.to(model.device, non_blocking=True), target_weight.to(model.device, non_blocking=True),
-                                world_size=world_size)
+        trainer.lr, trainer.betas, trainer.eps = _adam_hyper(optimizer)
+        tw = target_weight.to(trainer.device, non_blocking=True) if use_tw else \
+            torch.ones(n, trainer.num_joints, 1, dtype=torch.float32, device=trainer.device)
+        loss = trainer.train_step(input.to(trainer.device, non_blocking=True).contiguous(),
+                                  target.to(trainer.device, non_blocking=True), tw, world_size=world_size)
+        if not isinstance(model, HRNetTrainer):
+            model._stale = True
         total += loss * n
         count += n
     return float(total.sum().item()) / max(count, 1)
@@ -130,6 +191,8 @@ def validate(config, val_loader, val_dataset, model, criterion=None, output_dir=
     all_boxes = np.zeros((num_samples, 6))
     image_path, idx = [], 0
     loss_sum, loss_n = 0.0, 0
+    if hasattr(model, "eval"):
+        model.eval()                                       # function.py:121: switch to evaluate mode
     for input, target, target_weight, meta in val_loader:
         x = input.to(model.device if model.device is not None else "cuda").contiguous()
         n = x.shape[0]

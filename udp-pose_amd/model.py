@@ -28,6 +28,10 @@ class PoseHighResolutionNetHip:
 
     def __init__(self, cfg, dtype="f32", psa=False):
         self.psa = bool(psa)
+        self.cfg = cfg
+        self.training = False
+        self._trainer = None         # train.HRNetTrainer over the same weights (created by .train())
+        self._stale = False          # the trainer has stepped since the inference program was compiled
         self.extra = _get(cfg, "MODEL", "EXTRA")
         self.num_joints = int(_get(cfg, "MODEL", "NUM_JOINTS"))
         self.target_type = _get(cfg, "MODEL", "TARGET_TYPE")
@@ -60,7 +64,74 @@ class PoseHighResolutionNetHip:
         return self
 
     def state_dict(self):
+        """Reference-format state_dict; after training steps it is read back from the trainer's flat buffer."""
+        if self._trainer is not None and self._stale:
+            self._sync_from_trainer()
         return dict(self._sd or {})
+
+    def init_weights(self, pretrained=""):
+        """pose_hrnet.py:473-505: conv weights ~ N(0, 0.001), conv biases 0, BatchNorm (weight 1, bias 0; running
+        statistics at their nn.BatchNorm2d defaults 0 / 1), then the layers of a pretrained file named by
+        MODEL.EXTRA.PRETRAINED_LAYERS ('*' = all; 'stage4.2.fuse_layers' keys skipped as :492-493 does).  Draws come
+        from torch's global generator like nn.init.normal_ (module iteration order is not reproduced, so the
+        values differ from the reference's for the same seed; the distribution is the same)."""
+        import os
+        shapes = hrnet_param_shapes(self.extra, self.num_joints, self.target_type, psa=self.psa)
+        sd = {}
+        for k, shape in shapes.items():
+            if k.endswith("num_batches_tracked"):
+                sd[k] = torch.zeros((), dtype=torch.int64)
+            elif k.endswith("running_var"):
+                sd[k] = torch.ones(shape)
+            elif k.endswith("running_mean"):
+                sd[k] = torch.zeros(shape)
+            elif len(shape) == 4:
+                sd[k] = torch.randn(shape) * 0.001
+            elif k.endswith(".weight") and (k[:-7] + ".running_mean") in shapes:
+                sd[k] = torch.ones(shape)                 # BatchNorm weight
+            else:
+                sd[k] = torch.zeros(shape)                # BatchNorm / conv bias
+        if pretrained and os.path.isfile(pretrained):
+            layers = list(self.extra.get("PRETRAINED_LAYERS", ["*"]))
+            for name, v in torch.load(pretrained, map_location="cpu", weights_only=True).items():
+                name = name[7:] if name.startswith("module.") else name
+                if "stage4.2.fuse_layers" in name or name not in sd:
+                    continue
+                if layers[0] == "*" or name.split(".")[0] in layers:
+                    if tuple(v.shape) != tuple(sd[name].shape):
+                        raise RuntimeError("size mismatch for %s: %s vs %s" % (name, tuple(v.shape), tuple(sd[name].shape)))
+                    sd[name] = v
+        elif pretrained:
+            raise ValueError("%s is not exist!" % pretrained)       # pose_hrnet.py:503-505
+        self._sd = sd
+        self._trainer = None
+        self._release()
+        return self
+
+    # ---- training surface (function.train drives it; tools/train.py:91,116-125)
+    def trainer(self):
+        """The HRNetTrainer over this model's weights (created on first use from the current state_dict)."""
+        if self._trainer is None:
+            if self.psa:
+                raise NotImplementedError("pose_hrnet_psa: the training step does not cover the attention ops")
+            if self._sd is None:
+                raise RuntimeError("load_state_dict() or init_weights() first")
+            from .train import HRNetTrainer
+            if self.device is None:
+                self.to("cuda")
+            self._trainer = HRNetTrainer(self.cfg, self._sd, device=self.device, dtype="bf16" if self.dtype == "bf16" else "f32")
+        return self._trainer
+
+    def parameters(self):
+        """What ``optim.Adam(model.parameters(), lr=...)`` (utils.py:70-74) takes: ONE flat fp32 device tensor
+        holding every parameter in named_parameters() order (the trainer's master copy)."""
+        t = self.trainer()
+        return [t.flat[:t._n_param]]
+
+    def _sync_from_trainer(self):
+        self._sd = self._trainer.state_dict()
+        self._stale = False
+        self._release()
 
     def to(self, device):
         self.device = torch.device(device)
@@ -70,12 +141,14 @@ class PoseHighResolutionNetHip:
         return self.to("cuda")
 
     def eval(self):
-        return self
+        return self.train(False)
 
     def train(self, mode=True):
+        """nn.Module.train(): in training mode ``model(x)`` is the train-mode forward of the trainer (batch
+        statistics, tape kept for the backward); in eval mode the compiled inference program."""
         if mode:
-            raise NotImplementedError("udp-pose_amd round 1 implements the inference path; training "
-                                      "(backward kernels) is not built yet")
+            self.trainer()
+        self.training = bool(mode)
         return self
 
     # ---- compile / run
@@ -138,6 +211,8 @@ class PoseHighResolutionNetHip:
             self.to(x.device)
         if not x.is_cuda:
             raise RuntimeError("udp-pose_amd has no CPU path: the input must live on the GPU")
+        if self._trainer is not None and self._stale:
+            self._sync_from_trainer()                      # weights moved since the program was compiled
         if x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3:
             raise ValueError("expected fp32 [N,3,H,W], got %s %s" % (x.dtype, tuple(x.shape)))
         n, _, h, w = x.shape
@@ -186,6 +261,8 @@ class PoseHighResolutionNetHip:
         return np.frombuffer(ms, dtype=np.float32).copy(), prog.describe()
 
     def __call__(self, x):
+        if self.training:
+            return self.trainer().forward(x.contiguous())
         return self.raw_forward(x, flip_test=False)
 
     forward = __call__
@@ -228,10 +305,20 @@ class RSN18Hip(PoseHighResolutionNetHip):
 
 
 def get_pose_net(cfg, is_train, **kwargs):
-    """pose_hrnet.py:508-514.  ``is_train`` must be False in this round."""
+    """pose_hrnet.py:508-514: ``init_weights(cfg.MODEL.PRETRAINED)`` when ``is_train and cfg.MODEL.INIT_WEIGHTS``."""
+    model = PoseHighResolutionNetHip(cfg, **kwargs)
     if is_train:
-        raise NotImplementedError("training path (backward kernels) is not part of round 1")
-    return PoseHighResolutionNetHip(cfg, **kwargs)
+        try:
+            init = bool(_get(cfg, "MODEL", "INIT_WEIGHTS"))
+        except (KeyError, AttributeError):
+            init = False
+        if init:
+            try:
+                pretrained = _get(cfg, "MODEL", "PRETRAINED")
+            except (KeyError, AttributeError):
+                pretrained = ""
+            model.init_weights(pretrained or "")
+    return model
 
 
 def get_pose_net_psa(cfg, is_train, **kwargs):

@@ -418,3 +418,35 @@ def synth_accuracy_case(seed, max_shift, n=4, j=17, h=64, w=48):
     pred += 0.01 * rng.standard_normal(pred.shape).astype(np.float32)
     tgt[0, 3] = 0.0
     return pred, tgt
+
+
+def synth_keypoint_scene(n, h=128, w=96, num_joints=17, seed=0):
+    """Learnable synthetic pose data: every joint j is drawn as a small blob of its own colour on a noisy
+    background, so a network can be TRAINED to put a heat-map peak on it (the random-weight nets of the other
+    fixtures only produce noise-like maps).  Returns (uint8 crops [N,H,W,3], joints [N,J,3] in crop pixels with
+    sub-pixel positions, joints_vis [N,J,3])."""
+    rng = np.random.Generator(np.random.PCG64(0x5EED0 + seed))
+    hue = (np.arange(num_joints) + 0.5) / num_joints
+    colour = np.stack([0.5 + 0.5 * np.cos(2 * np.pi * (hue + k / 3.0)) for k in range(3)], axis=1)   # [J,3] in [0,1]
+    size = 2.0 + 1.5 * ((np.arange(num_joints) * 7) % 5) / 4.0                                        # blob sigma px
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    imgs = np.empty((n, h, w, 3), np.uint8)
+    joints = np.zeros((n, num_joints, 3), np.float32)
+    vis = np.ones((n, num_joints, 3), np.float32)
+    for i in range(n):
+        img = rng.uniform(0.0, 0.25, (h, w, 3)).astype(np.float32)
+        joints[i, :, 0] = rng.uniform(6, w - 7, num_joints)
+        joints[i, :, 1] = rng.uniform(6, h - 7, num_joints)
+        for j in range(num_joints):
+            g = np.exp(-((xx - joints[i, j, 0]) ** 2 + (yy - joints[i, j, 1]) ** 2) / (2 * size[j] ** 2))
+            img += g[:, :, None] * (0.75 * colour[j][None, None, :]).astype(np.float32)
+        imgs[i] = np.clip(img * 255.0, 0, 255).astype(np.uint8)
+    return imgs, joints, vis
+
+
+def normalize_u8(imgs_u8):
+    """ToTensor + ImageNet Normalize (pose_engine.py:40-43) of uint8 [N,H,W,3] -> fp32 [N,3,H,W]."""
+    x = np.transpose(imgs_u8.astype(np.float32) / np.float32(255), (0, 3, 1, 2))
+    mean = np.asarray(IMAGENET_MEAN, np.float32)[None, :, None, None]
+    std = np.asarray(IMAGENET_STD, np.float32)[None, :, None, None]
+    return ((x - mean) / std).astype(np.float32)
