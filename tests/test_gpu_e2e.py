@@ -165,10 +165,16 @@ def _dark_shift(hm):
     return np.abs(res - coords).max(axis=2)
 
 
-def test_w32_batch64_properties(w32_gaussian):
-    """Config-2 size: per-image results do not depend on the batch they ride in, the mirrored half
-    equals an explicit forward of mirrored inputs, hipGraph replay equals eager launches."""
-    _, net = w32_gaussian
+@pytest.mark.parametrize("dtype", ["f16x2", "bf16", "f32"])
+def test_w32_batch64_properties(w32_gaussian, dtype):
+    """Config 2 at its own size (N = 64, flip test on -> 128 images per launch sequence) in every storage mode
+    bench.py times: per-image results do not depend on the batch they ride in, the mirrored half equals an
+    explicit forward of mirrored inputs, hipGraph replay equals eager launches (merged branch launches, fused
+    blocks, the tile chooser's >= 512-workgroup rule at 128 images) -- all bit for bit."""
+    sd, net = w32_gaussian
+    if dtype != "f32":
+        net = MODELS["pose_hrnet"](_cfg(synth.W32_EXTRA, 17, "gaussian"), is_train=False, dtype=dtype)
+        net.load_state_dict(sd).to("cuda")
     x = torch.from_numpy(synth.synth_crops(8, 256, 192, seed=33)).cuda().repeat(8, 1, 1, 1)   # N = 64
     x[40:] += 0.01 * torch.randn(24, 3, 256, 192, device="cuda", generator=torch.Generator("cuda").manual_seed(1))
     raw = net.raw_forward(x, flip_test=True).clone()

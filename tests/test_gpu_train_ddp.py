@@ -52,6 +52,52 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _worker_w32(rank, world, port, q, backend):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": dev} if backend == "nccl" else {}))
+    try:
+        from udp_pose_amd.train import HRNetTrainer
+        cfg = {"MODEL": {"EXTRA": synth.W32_EXTRA, "NUM_JOINTS": 17, "TARGET_TYPE": "gaussian"}}
+        tr = HRNetTrainer(cfg, synth.synth_state_dict(synth.W32_EXTRA, 17, "gaussian", seed=0), device=dev)
+        n = 32
+        x = torch.from_numpy(np.tile(synth.synth_crops(8, 256, 192, seed=50 + rank), (4, 1, 1, 1)))
+        tg = torch.from_numpy(synth.synth_heatmaps(n, 17, 64, 48, seed=60 + rank))
+        for _ in range(2):
+            loss = tr.train_step(x.to(dev), tg.to(dev), torch.ones(n, 17, 1, device=dev), world_size=world)
+        torch.cuda.synchronize()
+        p = tr.flat[:tr._n_param]
+        q.put((rank, bool(torch.isfinite(p).all()), float(p.double().sum()), float((p.double() ** 2).sum()),
+               p[::997].cpu().numpy(), float(loss.cpu()[0])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_w32_config3_size_replicas_stay_identical():
+    """Config 3 at its per-GPU size (W32 256x192, 32 images per rank), two ranks, two steps through the SUM
+    all-reduce of the flat 28.6 M-element gradient: parameters finite and identical on both ranks.  With two
+    visible GPUs the transport is RCCL (backend nccl, one device per rank); on the one-GPU test box both ranks
+    share the device and gloo carries the all-reduce."""
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_w32, args=(r, 2, port, q, backend)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0][1] and res[1][1]
+    assert res[0][2] == res[1][2] and res[0][3] == res[1][3]
+    np.testing.assert_array_equal(res[0][4], res[1][4])
+    assert np.isfinite(res[0][5]) and np.isfinite(res[1][5])
+
+
 def test_two_rank_train_step_equals_summed_shard_gradients():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

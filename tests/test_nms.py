@@ -45,6 +45,24 @@ def test_hip_oks_nms_matches_reference(golden_dir):
 
 
 @pytest.mark.gpu
+def test_hip_oks_nms_with_nan_scores_equals_numpy_order():
+    """A NaN score (e.g. from a NaN maxval) must not break the kernel's ranking: NumPy's argsort puts NaN last,
+    so the reference's ``scores.argsort()[::-1]`` visits it FIRST; the kernel ranks NaN as +inf and keeps the same
+    list as the oracle (which runs the reference's NumPy statements)."""
+    from udp_pose_amd import nms as u_nms
+    kpts, areas, scores, offs = synth.synth_person_sets(4, 5)
+    for i in range(4):
+        a, b = offs[i], offs[i + 1]
+        sc = scores[a:b].copy()
+        sc[(i + 1) % (b - a)] = np.nan
+        if b - a > 3:
+            sc[3] = np.nan
+        db = [{"keypoints": kpts[p], "area": areas[p], "score": sc[p - a]} for p in range(a, b)]
+        want = o_nms.oks_nms(kpts[a:b].reshape(b - a, -1), sc, areas[a:b], 0.5, None, None)
+        assert u_nms.oks_nms(db, 0.5, None, None) == want, (i, want)
+
+
+@pytest.mark.gpu
 def test_hip_rescore_and_nms_whole_evaluation():
     """coco.py:306-356 in one launch vs the oracle's per-image loop (rescoring restated from the text)."""
     from udp_pose_amd import nms as u_nms

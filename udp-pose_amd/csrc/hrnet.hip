@@ -450,8 +450,15 @@ extern "C" int udp_hrnet_profile(udp_hrnet* h, const float* in_nchw, int n, int 
   rc = describe_all(h, in_nchw, n, flip_test ? 1 : 0, reinterpret_cast<char*>(workspace), heatmaps_nchw, L);
   if (rc) return rc;
   const size_t nops = h->ops.size();
-  std::vector<hipEvent_t> ev(2 * nops);
-  for (auto& e : ev) UDP_HIP_CHECK(hipEventCreate(&e));
+  std::vector<hipEvent_t> ev(2 * nops, nullptr);
+  for (auto& e : ev) {
+    const hipError_t ce = hipEventCreate(&e);
+    if (ce != hipSuccess) {
+      for (auto& d : ev)
+        if (d) (void)hipEventDestroy(d);
+      return fail(UDP_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(ce));
+    }
+  }
   rc = enqueue_all(h, L, s, ev.data(), 0);
   hipError_t se = hipStreamSynchronize(s);
   if (!rc && se == hipSuccess) {
@@ -479,11 +486,17 @@ extern "C" int udp_hrnet_forward(udp_hrnet* h, const float* in_nchw, int n, int 
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   flip_test = flip_test ? 1 : 0;
   if (use_graph)
-    for (auto& g : h->graphs)
+    for (size_t k = 0; k < h->graphs.size(); ++k) {
+      const GraphEntry g = h->graphs[k];
       if (g.n == n && g.flip == flip_test && g.in == in_nchw && g.ws == workspace && g.out == heatmaps_nchw) {
+        if (k + 1 != h->graphs.size()) {   // most recently used last
+          h->graphs.erase(h->graphs.begin() + k);
+          h->graphs.push_back(g);
+        }
         UDP_HIP_CHECK(hipGraphLaunch(g.exec, s));
         return UDP_OK;
       }
+    }
   std::vector<Launch> L;
   rc = describe_all(h, in_nchw, n, flip_test, reinterpret_cast<char*>(workspace), heatmaps_nchw, L);
   if (rc) return rc;
@@ -498,6 +511,9 @@ extern "C" int udp_hrnet_forward(udp_hrnet* h, const float* in_nchw, int n, int 
   rc = build_graph(h, L, &e.graph, &e.exec);
   if (rc) return rc;
   if (h->graphs.size() >= 8) {
+    // evict the least recently used graph; its last replay may still be running on the (single) stream of
+    // this handle -> drain the stream before the executable goes away
+    UDP_HIP_CHECK(hipStreamSynchronize(s));
     (void)hipGraphExecDestroy(h->graphs[0].exec);
     (void)hipGraphDestroy(h->graphs[0].graph);
     h->graphs.erase(h->graphs.begin());

@@ -52,9 +52,14 @@ __global__ __launch_bounds__(256) void oks_nms_kernel(const float* __restrict__ 
   }
   __syncthreads();
   for (int p = t; p < P; p += 256) {
+    // rank = position in scores.argsort()[::-1] (nms.py:95).  NumPy sorts NaN last, so reversed it comes
+    // FIRST: rank with NaN = +inf -- a total order, every order[] slot is written exactly once
     int r = 0;
-    const double s = sc[p];
-    for (int q = 0; q < P; ++q) r += (sc[q] > s) || (sc[q] == s && q > p);
+    const double s = sc[p] != sc[p] ? (double)INFINITY : sc[p];
+    for (int q = 0; q < P; ++q) {
+      const double sq = sc[q] != sc[q] ? (double)INFINITY : sc[q];
+      r += (sq > s) || (sq == s && q > p);
+    }
     order[r] = p;
   }
   __syncthreads();
@@ -66,11 +71,13 @@ __global__ __launch_bounds__(256) void oks_nms_kernel(const float* __restrict__ 
     for (int k = 0; k < P && k < 20; ++k) {
       double bv = -1.0;
       int bi = -1;
-      for (int q = t; q < P; q += 256)
-        if (!dead[q] && (sc[q] > bv || (sc[q] == bv && q > bi))) {
-          bv = sc[q];
+      for (int q = t; q < P; q += 256) {
+        const double sq = sc[q] != sc[q] ? (double)INFINITY : sc[q];     // np.argmax picks a NaN first as well
+        if (!dead[q] && (sq > bv || (sq == bv && q > bi))) {
+          bv = sq;
           bi = q;
         }
+      }
       red_v[t] = bv;
       red_i[t] = bi;
       __syncthreads();

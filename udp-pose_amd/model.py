@@ -26,6 +26,9 @@ def _get(cfg, *path):
 class PoseHighResolutionNetHip:
     """HRNet (UDP variant) inference on MI355X through the C ABI."""
 
+    MAX_IO_SHAPES = 8      # persistent (input, output) buffer pairs kept, least recently used evicted (= the
+                           # library's hipGraph cache size: one graph per buffer set)
+
     def __init__(self, cfg, dtype="f32", psa=False):
         self.psa = bool(psa)
         self.cfg = cfg
@@ -193,13 +196,15 @@ class PoseHighResolutionNetHip:
         if self.device is None:
             self.to("cuda")
         key = (n, h, w, bool(flip_test))
-        io = self._io.get(key)
+        io = self._io.pop(key, None)
         if io is None:
             prog = self.program(h, w)
             b = n * (2 if flip_test else 1)
             io = (torch.empty(n, 3, h, w, dtype=torch.float32, device=self.device),
                   torch.empty(b, prog.out_channels, h // 4, w // 4, dtype=torch.float32, device=self.device))
-            self._io[key] = io
+            while len(self._io) >= self.MAX_IO_SHAPES:     # least recently used first (dicts keep insertion order)
+                self._io.pop(next(iter(self._io)))
+        self._io[key] = io                                  # (re-)inserted last = most recently used
         return io
 
     def raw_forward(self, x, flip_test=False):

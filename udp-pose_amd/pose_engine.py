@@ -117,28 +117,45 @@ class UdpPsaPoseHip:
     def _box_to_center_scale(self, boxes, pixel_std=200):
         return box_to_center_scale(boxes, self.input_shape, pixel_std)
 
+    @staticmethod
+    def _bucket(n):
+        """Batch size the network is run at for n boxes: 1, 2, 4, 8, then multiples of 8.  A frame's box count
+        changes almost every call; per exact n the model would keep one set of I/O buffers and one hipGraph
+        (instantiated from ~170 launch descriptions) -- bucketing bounds both.  The padding rows repeat the last
+        box and are dropped from the result (an image's heat-maps do not depend on its batch, bit for bit:
+        tests/test_gpu_e2e.py::test_each_image_is_independent_of_its_batch)."""
+        if n <= 8:
+            b = 1
+            while b < n:
+                b *= 2
+            return b
+        return (n + 7) // 8 * 8
+
     def _preprocess(self, img, boxes):
         cs = self._box_to_center_scale(boxes)
         if cs.shape[0] == 0:
             raise RuntimeError("infer_pose needs at least one box (the reference's torch.stack([]) raises)")
-        mats = np.stack([engine_affine_dst2src(c[:2], c[2:], self.input_shape) for c in cs])
+        n = cs.shape[0]
+        nb = self._bucket(n)
+        cs_run = np.concatenate([cs, np.repeat(cs[-1:], nb - n, axis=0)]) if nb > n else cs
+        mats = np.stack([engine_affine_dst2src(c[:2], c[2:], self.input_shape) for c in cs_run])
         frame = torch.as_tensor(np.ascontiguousarray(img, dtype=np.uint8)).to(self._device, non_blocking=True)
         w, h = int(self.input_shape[0]), int(self.input_shape[1])
-        xin, _ = self.model.io_buffers(cs.shape[0], h, w, False)
+        xin, _ = self.model.io_buffers(nb, h, w, False)
         return warp_affine_device(frame, mats, (h, w), out=xin), cs
 
     @torch.no_grad()
     def infer_pose(self, img, boxes, flip_test=False):
         pose_input, cs = self._preprocess(img, boxes)
-        n = cs.shape[0]
+        n, nb = cs.shape[0], pose_input.shape[0]
         offset = self.config.MODEL.TARGET_TYPE == "offset"
         if flip_test:
-            xin, _ = self.model.io_buffers(n, pose_input.shape[2], pose_input.shape[3], True)
+            xin, _ = self.model.io_buffers(nb, pose_input.shape[2], pose_input.shape[3], True)
             xin.copy_(pose_input)
             raw = self.model.raw_forward(xin, flip_test=True)
-            hm = flip_fuse(raw[:n], raw[n:], self.flip_pairs, offset)
+            hm = flip_fuse(raw[:n], raw[nb:nb + n], self.flip_pairs, offset)
         else:
-            hm = self.model.raw_forward(pose_input)
+            hm = self.model.raw_forward(pose_input)[:n]
         center = torch.from_numpy(cs[:, :2].astype(np.float64))
         scale = torch.from_numpy(cs[:, 2:].astype(np.float64))
         post = bool(self.config.TEST.POST_PROCESS) and not offset
