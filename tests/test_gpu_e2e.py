@@ -402,3 +402,63 @@ def test_each_image_is_independent_of_its_batch(dtype):
         torch.testing.assert_close(one[1], whole[5 + i], rtol=0, atol=0)
     two = net.raw_forward(xd[3:5].contiguous(), flip_test=False).clone()
     torch.testing.assert_close(two, whole[3:5], rtol=0, atol=0)
+
+
+def _peaked(golden_dir):
+    g = np.load(os.path.join(golden_dir, "hrnet_peaked.npz"))
+    extra = synth.scaled_extra(16, modules=(1, 1, 1), blocks=1)
+    sd = {k[3:]: torch.from_numpy(g[k].astype(np.float32) if g[k].dtype == np.float16 else g[k]) for k in g.files if k.startswith("sd/")}
+    return g, extra, sd
+
+
+def _peaked_pipeline(g, extra, sd, dtype):
+    net = MODELS["pose_hrnet"](_cfg(extra, 17, "gaussian"), is_train=False, dtype=dtype).load_state_dict(sd).to("cuda")
+    x = torch.from_numpy(synth.normalize_u8(g["crops_u8"])).cuda()
+    n = x.shape[0]
+    raw = net.raw_forward(x, flip_test=True)
+    hm = flip_fuse(raw[:n], raw[n:], COCO_FLIP_PAIRS, False)
+    preds, maxvals, _, idx = decode_device(hm, torch.from_numpy(g["center"].astype(np.float64)),
+                                           torch.from_numpy(g["scale"].astype(np.float64)), "gaussian", True, 4.0,
+                                           cs_is_f32=g["center"].dtype == np.float32, want_idx=True)
+    return raw.cpu().numpy(), hm.cpu().numpy(), preds.cpu().numpy(), maxvals.cpu().numpy(), idx.cpu().numpy()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16x2"])
+def test_trained_peaked_maps_end_to_end_keypoints_all_joints(golden_dir, dtype):
+    """The whole hot path (forward + mirrored forward + flip fuse + DARK decode) on TRAINED, peaked heat-maps against
+    what the REFERENCE module + reference get_final_preds produced (tests/golden/hrnet_peaked.npz): north-star
+    tolerances on EVERY joint -- heat-maps 1e-3, arg-max identical, keypoints 1e-3 px in image space -- for the
+    fp32 mode and for the split-fp16 throughput mode.  (On the random-weight fixtures DARK's Hessian is
+    ill-conditioned for many joints; here it is not, so no joint is excluded.)"""
+    g, extra, sd = _peaked(golden_dir)
+    raw, hm, preds, maxvals, idx = _peaked_pipeline(g, extra, sd, dtype)
+    n = g["out"].shape[0]
+    np.testing.assert_allclose(raw[:n], g["out"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(raw[n:], g["out_flip"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(hm, g["fused"], rtol=0, atol=1e-3)
+    np.testing.assert_array_equal(idx, g["fused"].reshape(n, 17, -1).argmax(2))
+    np.testing.assert_allclose(maxvals, g["maxvals"], rtol=0, atol=1e-3)
+    err = np.abs(preds - g["preds"]).max()
+    print("%s peaked end-to-end: heat-map max err %.3g, keypoint max err %.3g px (all %d joints)"
+          % (dtype, np.abs(hm - g["fused"]).max(), err, preds.shape[0] * preds.shape[1]))
+    np.testing.assert_allclose(preds, g["preds"], rtol=0, atol=1e-3)
+
+
+def test_trained_peaked_maps_bf16_storage_bound(golden_dir):
+    """What bf16 storage (reduced precision, NOT the parity mode) does to trained, peaked heat-maps: stated bounds,
+    far looser than the contract -- heat-maps within 0.02 (peaks are ~0.4..1.3; measured 5.4e-3), arg-max
+    identical for >= 90 % of the joints and identical or adjacent for >= 95 % (measured 94 % / 98.5 %), keypoints
+    within 0.05 heat-map pixels at the 95th percentile (measured 0.01; a joint whose arg-max flips between two
+    near-equal peaks moves by pixels -- the maximum is reported, not gated)."""
+    g, extra, sd = _peaked(golden_dir)
+    raw, hm, preds, maxvals, idx = _peaked_pipeline(g, extra, sd, "bf16")
+    n = hm.shape[0]
+    ref_idx = g["fused"].reshape(n, 17, -1).argmax(2)
+    w = hm.shape[3]
+    d = np.maximum(np.abs(idx % w - ref_idx % w), np.abs(idx // w - ref_idx // w))
+    px = np.abs(preds - g["preds"]).max(axis=2) / (g["scale"][:, :1] * 200.0 / (w - 1))      # in heat-map pixels
+    print("bf16 peaked: heat-map max err %.3g, arg-max equal %.3f / adjacent %.3f, keypoint err (heat-map px) median %.3g p95 %.3g max %.3g"
+          % (np.abs(hm - g["fused"]).max(), (d == 0).mean(), (d <= 1).mean(), np.median(px), np.percentile(px, 95), px.max()))
+    assert np.abs(hm - g["fused"]).max() < 0.02
+    assert (d == 0).mean() >= 0.9 and (d <= 1).mean() >= 0.95
+    assert np.percentile(px, 95) < 0.05

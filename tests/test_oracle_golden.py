@@ -233,3 +233,26 @@ def test_accuracy_matches_reference(golden_dir):
         assert abs(avg - float(g["avg%d" % k])) < 1e-12 and cnt == int(g["cnt%d" % k])
         np.testing.assert_array_equal(p, g["p%d" % k])
     assert 0.1 < float(g["avg1"]) < 0.9                       # a case that is neither all right nor all wrong
+
+
+def test_oracle_reproduces_the_trained_peaked_fixture(golden_dir):
+    """tests/golden/hrnet_peaked.npz (oracle/gen_golden_peaked.py): a mini HRNet TRAINED by the reference module +
+    reference JointsMSELoss + torch.optim.Adam until its heat-maps have clear peaks.  The oracle's forward, flip
+    fusion and get_final_preds reproduce the reference's outputs on the held-out crops."""
+    import torch
+    from oracle import decode as odec, flip as oflip, hrnet as ohrnet
+    from udp_pose_amd import synth
+    g = np.load(os.path.join(golden_dir, "hrnet_peaked.npz"))
+    extra = synth.scaled_extra(16, modules=(1, 1, 1), blocks=1)
+    sd = {k[3:]: torch.from_numpy(g[k].astype(np.float32) if g[k].dtype == np.float16 else g[k]) for k in g.files if k.startswith("sd/")}
+    x = torch.from_numpy(synth.normalize_u8(g["crops_u8"]))
+    out = ohrnet.hrnet_forward(sd, extra, x).numpy()
+    np.testing.assert_allclose(out, g["out"], rtol=0, atol=1e-5)
+    assert float(g["argmax_hit_rate"]) > 0.9 and g["out"].max() > 1.0            # peaked, not noise-like
+    out_flip = ohrnet.hrnet_forward(sd, extra, torch.flip(x, dims=[3])).numpy()
+    fused = oflip.flip_fuse(out, out_flip, oflip.COCO_FLIP_PAIRS, False)
+    np.testing.assert_allclose(fused, g["fused"], rtol=0, atol=1e-5)
+    p, m, pin, _ = odec.get_final_preds("gaussian", True, 4.0, g["fused"].copy(), g["center"], g["scale"])
+    np.testing.assert_allclose(p, g["preds"], rtol=0, atol=1e-9)
+    np.testing.assert_array_equal(m, g["maxvals"])
+    np.testing.assert_allclose(pin, g["preds_in_input_space"], rtol=0, atol=1e-9)
