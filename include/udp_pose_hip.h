@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UDP_POSE_ABI_VERSION 12
+#define UDP_POSE_ABI_VERSION 13
 
 enum udp_status {
   UDP_OK = 0,
@@ -113,7 +113,12 @@ typedef struct udp_conv_op {
   int64_t w2_off, b2_off;  /* UDP_OP_BLOCK: the second conv's weights / bias in the blob */
   int32_t group;           /* != 0: consecutive UDP_OP_CONV ops with the same group id are independent of each
                               other (same-depth convs of different HRNet branches) and may share one launch */
-  int32_t reserved;
+  int32_t wfmt;            /* weight layout of a UDP_OP_CONV.  0: [tap][cout_pad][cin] in dtype (UDP_F16X2: per row the
+                              cin hi values, then the cin lo values).  1 (UDP_F16X2 only): fragment-major for the
+                              weight-stationary kernel -- 1 KiB blocks [tap][cin chunk of 32][cout pair of 32]
+                              [block nb of 16][plane hi|lo], a block = 64 lanes x 8 fp16: lane kg*16 + li holds
+                              w[tap][32*pair + 8*(li>>2) + 4*nb + (li&3)][32*chunk + 8*kg .. +7] (cin zero-padded to
+                              a multiple of 32).  udp_pose_amd.f16x2.pack_weights_ws builds it. */
 } udp_conv_op;
 
 typedef struct udp_hrnet udp_hrnet; /* opaque */

@@ -358,7 +358,7 @@ def test_fused_basic_block_equals_the_two_conv_launches(h, w, monkeypatch):
     assert e_f < 1.15 * e_u + 1e-4, (e_f, e_u)
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "f16x2"])
+@pytest.mark.parametrize("dtype", ["bf16", "f16x2", "f16x2-ws"])
 def test_merged_branch_launches_equal_separate_launches(monkeypatch, dtype):
     """bf16 graph mode: the same-depth convs of different branches run as ONE conv_mfma_multi launch
     (hrnet.hip build_graph).  Per output element the accumulation order does not depend on the tile
@@ -368,6 +368,8 @@ def test_merged_branch_launches_equal_separate_launches(monkeypatch, dtype):
     x = torch.from_numpy(synth.synth_crops(5, 128, 96, seed=15))
     ohrnet.hrnet_forward(sd, extra, x, calibrate=True)
     outs = {}
+    monkeypatch.setenv("UDP_POSE_WS", "1" if dtype.endswith("-ws") else "0")     # weight-stationary kernel family
+    dtype = dtype.split("-")[0]
     for mode in ("grouped", "eager", "plain"):
         if mode == "plain":
             monkeypatch.setenv("UDP_POSE_NO_GROUPS", "1")

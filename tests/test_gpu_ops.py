@@ -39,6 +39,8 @@ def _adversarial(hm, k):
 def _conv_case(dtype, ks, stride, cin, cout, h, w, n, relu, res, nup, nchw_out=False, seed=0):
     rng = np.random.Generator(np.random.PCG64(seed))
     tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    ws = dtype == "f16x2-ws"          # split fp16 on the weight-stationary kernel (fragment-major weights)
+    dtype = "f16x2" if ws else dtype
     h2 = dtype == "f16x2"
     q = (lambda t: f16x2.decode(f16x2.encode(t))) if h2 else (lambda t: t)     # operands exactly as the device holds them
     pad = ks // 2
@@ -64,7 +66,7 @@ def _conv_case(dtype, ks, stride, cin, cout, h, w, n, relu, res, nup, nchw_out=F
     bp = torch.zeros(cout_pad)
     bp[:cout] = bias
     nhwc = lambda t: (f16x2.encode(t.permute(0, 2, 3, 1)) if h2 else t.permute(0, 2, 3, 1).contiguous()).cuda()
-    d_x, d_w, d_b = nhwc(x), (f16x2.encode(wp) if h2 else wp).cuda(), bp.cuda()
+    d_x, d_w, d_b = nhwc(x), (f16x2.pack_weights_ws(wp) if ws else f16x2.encode(wp) if h2 else wp).cuda(), bp.cuda()
     d_r = nhwc(r) if r is not None else None
     d_u = [nhwc(t) for t in ups] + [None] * (3 - nup)
     op = _lib.ConvOp()
@@ -72,6 +74,7 @@ def _conv_case(dtype, ks, stride, cin, cout, h, w, n, relu, res, nup, nchw_out=F
     op.cin, op.cout, op.cout_pad = cin, cout, cout_pad
     op.hin, op.win, op.hout, op.wout = h, w, ho, wo
     op.n_up = nup
+    op.wfmt = int(ws)
     for u in range(nup):
         op.up_shift[u] = u + 1
     if nchw_out:
@@ -115,7 +118,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f16x2", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "f16x2", "f16x2-ws", "bf16"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "k%ds%d_%d-%d_%dx%d_n%d" % c[:7])
 def test_fused_conv_matches_torch_fp32(case, dtype):
     got, ref = _conv_case(dtype, *case)
@@ -127,7 +130,7 @@ def test_fused_conv_matches_torch_fp32(case, dtype):
     # fp32 accumulation order + one bf16 rounding of the output (2^-9 relative).
     tol = 6e-3 * scale if dtype == "bf16" else 1e-4 * scale
     np.testing.assert_allclose(got, ref, rtol=0, atol=tol)
-    if dtype == "f16x2":
+    if dtype.startswith("f16x2"):
         assert np.abs(got - ref).max() <= 2e-5 * scale, np.abs(got - ref).max()
 
 

@@ -38,6 +38,7 @@ def run(dtype, n, shape, reps=20):
     op.kind, op.ks, op.stride, op.relu = _lib.UDP_OP_CONV, ks, st, 1
     op.cin, op.cout, op.cout_pad = cin, cout, cout
     op.hin, op.win, op.hout, op.wout = hi, wi, ho, wo
+    op.wfmt = int(os.environ.get("UDP_POSE_WS", "1") != "0" and dtype == "f16x2")
     call = lambda: _lib.check(_lib.lib().udp_conv2d_fused(C.byref(op), _lib.DTYPES[dtype], n, _lib.ptr(x), _lib.ptr(w),
                                                           _lib.ptr(b), _lib.ptr(r), None, None, None, _lib.ptr(out),
                                                           _lib.stream_ptr()))

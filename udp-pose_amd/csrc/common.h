@@ -57,6 +57,7 @@ struct ConvParams {
   int out_nchw_f32;      // epilogue writes NCHW fp32 (network output) instead of NHWC T
   int flip_from;         // stem only: images >= flip_from read image (n - flip_from) mirrored in x
   int sbuf;              // conv_mfma_kernel: one stage buffer instead of two (set by conv_choose_tile)
+  int wfmt;              // udp_conv_op.wfmt: 1 = fragment-major split-fp16 weights (conv_ws_h2_kernel)
 };
 
 // Kernel argument of conv_mfma_multi: up to 4 independent convs in one launch (flat block index ->
@@ -65,6 +66,7 @@ struct ConvMulti {
   ConvParams p[4];
   unsigned start[5];      // first flat block of sub-problem j; unused entries 0xFFFFFFFF, start[4] = total
   unsigned tiles[4];      // tiles (grid.x) of sub-problem j
+  int code[4];            // conv_ws_multi: cout pairs per workgroup (CP) of sub-problem j
 };
 
 }  // namespace udp
@@ -76,6 +78,7 @@ struct Launch {
   dim3 grid, block;
   unsigned lds = 0;
   int groupable = 0;   // conv described by describe_conv_grouped: may be merged with its group siblings
+  int ws_cp = 0;       // weight-stationary member: its cout pairs per workgroup
   ConvParams p;
 };
 }  // namespace udp

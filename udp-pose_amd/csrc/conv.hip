@@ -624,7 +624,7 @@ __global__ __launch_bounds__(NW * 64) void conv_mfma_kernel(const ConvParams p) 
 //   pg*PB .. pg*PB+PB-1 of the tile (M <= 16*PB*PG pixels) x couts (blockIdx.y*CP + cp)*32 .. +31.
 // ---------------------------------------------------------------------------------------------
 template <int KS, int STRIDE, int PB, int CP, bool NCHW>
-__global__ __launch_bounds__(256, 2) void conv_ws_h2_kernel(const ConvParams p) {
+__device__ __forceinline__ void conv_ws_body(const ConvParams& p, const int tile_id, const int cby) {
   using T = H2;
   constexpr int CK = 32, ESZ = 2, NB = 2, NW = 4;
   constexpr int PAD = KS / 2, TAPS = KS * KS;
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(256, 2) void conv_ws_h2_kernel(const ConvParams p) 
   const int kg = lane >> 4;
   const int cp = wave % CP, pg = wave / CP;          // 4 waves = CP cout pairs x 4/CP pixel groups
 
-  int t = blockIdx.x;   // wave-uniform tile decode
+  int t = tile_id;   // wave-uniform tile decode
   const int tx = t % p.tiles_x;
   t /= p.tiles_x;
   const int ty = t % p.tiles_y;
@@ -655,17 +655,17 @@ __global__ __launch_bounds__(256, 2) void conv_ws_h2_kernel(const ConvParams p) 
   const bool ragged = (p.Cin % CK) != 0;
   const int RT = p.R * p.TW;
   const int M = p.G * RT;
-  const unsigned cinb = (unsigned)p.Cin * ESZ * 2;
   const unsigned inpb = (unsigned)p.in_pitch * ESZ * 2;
   const unsigned outpb = (unsigned)p.out_pitch * ESZ * 2, respb = (unsigned)p.res_pitch * ESZ * 2;
-  const unsigned w_lo = (unsigned)p.Cin * ESZ, in_lo = (unsigned)p.in_pitch * ESZ;
+  const unsigned in_lo = (unsigned)p.in_pitch * ESZ;
   const unsigned out_lo = (unsigned)p.out_pitch * ESZ, res_lo = (unsigned)p.res_pitch * ESZ;
 
   const unsigned out_pix = (unsigned)p.N * p.Hout * p.Wout;
   const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void*>(p.in), 0, (unsigned)p.N * p.Hin * p.Win * inpb, 0x00020000);
+  const unsigned npairs = (unsigned)p.CoutPad >> 5;
   const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<void*>(p.wgt), 0, (unsigned)TAPS * p.CoutPad * cinb, 0x00020000);
+      const_cast<void*>(p.wgt), 0, (unsigned)TAPS * nchunks * npairs * 4096u, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(
       p.out, 0, NCHW ? out_pix * p.Cout * 4 : out_pix * outpb, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc(
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(256, 2) void conv_ws_h2_kernel(const ConvParams p) 
 
   // ---- the lane's PB output pixels
   int prow[PB], opix[PB], ocrd[PB];
-  const int cwave = (blockIdx.y * CP + cp) * 32;   // first cout of the wave's pair of blocks
+  const int cwave = (cby * CP + cp) * 32;   // first cout of the wave's pair of blocks
   const int cbase = cwave + 8 * kg;                // the lane's 8 consecutive output channels
 #pragma unroll
   for (int i = 0; i < PB; ++i) {
@@ -727,25 +727,22 @@ __global__ __launch_bounds__(256, 2) void conv_ws_h2_kernel(const ConvParams p) 
     ocrd[i] = ok ? (y | (xo << 10) | (n << 20)) : -1;
   }
 
-  // ---- weights: A-fragment row li of block nb is cout cwave + 8*(li>>2) + 4*nb + (li&3) (so that a lane ends
-  // up with 8 consecutive couts); its 8 K values are the lane's 16 bytes at kg*16 of the chunk's 64-byte row
-  unsigned wvoff[NB];
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) wvoff[nb] = (unsigned)(cwave + 8 * (li >> 2) + 4 * nb + (li & 3)) * cinb + kg * 16;
-  const unsigned tap_stride = (unsigned)p.CoutPad * cinb;
+  // ---- weights (fragment-major, udp_conv_op.wfmt == 1): the 1 KiB block (tap, chunk, cout pair, nb, plane) holds
+  // lane l's 8 K values at 16*l -- A-fragment row li of block nb is cout cwave + 8*(li>>2) + 4*nb + (li&3), so
+  // that a lane ends up with 8 consecutive couts.  One contiguous load per fragment; cin is zero-padded.
+  const unsigned wvoff = (unsigned)lane * 16u;
+  const unsigned wpair = (unsigned)(cby * CP + cp) * 4096u;
   // A fragments of one tap (2 blocks x hi/lo = 16 registers) in a ring of three: the fragments of step s + 2
   // stream in from L2 while step s feeds the MFMAs (step = one tap of one K chunk)
   f16x8 ah[3][NB], al[3][NB];
   const int nsteps = nchunks * TAPS;
   auto load_a = [&](int s, f16x8 (&h)[NB], f16x8 (&l)[NB]) __attribute__((always_inline)) {
     const int c = s / TAPS, tap = s - c * TAPS;
-    const bool dead = ragged && c == nchunks - 1 && kg >= (p.Cin - c * CK) / 8;
-    const unsigned soff = (unsigned)tap * tap_stride + (unsigned)c * (CK * ESZ);
+    const unsigned soff = (unsigned)(tap * nchunks + c) * (npairs * 4096u) + wpair;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-      const unsigned vo = dead ? kOobOff : wvoff[nb];
-      h[nb] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r_w, vo, soff, 0));
-      l[nb] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r_w, vo + w_lo, soff, 0));
+      h[nb] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r_w, wvoff + 2048u * nb, soff, 0));
+      l[nb] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r_w, wvoff + 2048u * nb + 1024u, soff, 0));
     }
   };
 
@@ -890,6 +887,27 @@ __global__ __launch_bounds__(256, 2) void conv_ws_h2_kernel(const ConvParams p) 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   UDP_STAMP(7);
 #endif
+}
+
+template <int KS, int STRIDE, int PB, int CP, bool NCHW>
+__global__ __launch_bounds__(256, 2) void conv_ws_h2_kernel(const ConvParams p) {
+  conv_ws_body<KS, STRIDE, PB, CP, NCHW>(p, blockIdx.x, blockIdx.y);
+}
+
+// Merged launch of up to 4 independent weight-stationary convs (same-depth convs of different HRNet branches):
+// every member runs the 6-pixel-blocks-per-wave body with its own cout-pair split (ConvMulti::code = CP).
+template <int KS>
+__global__ __launch_bounds__(256, 2) void conv_ws_multi(const ConvMulti m) {
+  const unsigned b = blockIdx.x;
+  const int j = (b >= m.start[1]) + (b >= m.start[2]) + (b >= m.start[3]);
+  const unsigned r = b - m.start[j];
+  const unsigned cby = r / m.tiles[j];
+  const int tile = (int)(r - cby * m.tiles[j]);
+  switch (m.code[j]) {
+    case 1: conv_ws_body<KS, 1, 6, 1, false>(m.p[j], tile, (int)cby); break;
+    case 2: conv_ws_body<KS, 1, 6, 2, false>(m.p[j], tile, (int)cby); break;
+    default: conv_ws_body<KS, 1, 6, 4, false>(m.p[j], tile, (int)cby); break;
+  }
 }
 
 // Horizontal fusion: up to 4 independent convs (the same-depth convs of different HRNet branches, which
@@ -1855,8 +1873,12 @@ static bool ws_tile(const ConvParams& p, int ks, int stride, int cp, int pb, WsT
   const int nstage = ceil_div(p.Cin, 32) > 1 ? 2 : 1;
   t->lds = (size_t)((npix(G, R) + 15) / 16) * 16 * ROWB * 2 * nstage;
   if (t->lds > 160 * 1024) return false;
+  // pixel blocks per wave the tile really needs (the halo limit may have shrunk it): the smallest instantiated
+  // count that covers them, so no wave idles under masked blocks
+  const int need = ceil_div(ceil_div(G * R * TW, 16), pg);
+  if (need > pb) return false;
   t->cp = cp;
-  t->pb = pb;
+  t->pb = need <= 2 ? 2 : need <= 3 ? 3 : need <= 4 ? 4 : 6;
   t->G = G;
   t->R = R;
   t->TW = TW;
@@ -1864,19 +1886,18 @@ static bool ws_tile(const ConvParams& p, int ks, int stride, int cp, int pb, WsT
   return true;
 }
 
-static int describe_conv_ws(ConvParams p, int ks, int stride, Launch* out) {
-  // Opt-in (UDP_POSE_WS=1) while it is slower than conv_mfma_kernel<H2> on most HRNet shapes: measured on
-  // MI355X its A-fragment loads (4 KiB per wave and tap from L2, half-used cache lines) cost ~25 % of the
-  // launch; see DESIGN.md "Weight-stationary experiment".
-  static const bool on = getenv("UDP_POSE_WS") != nullptr;
-  if (!on || stride != 1 || (ks != 3 && ks != 1) || p.out_nchw_f32) return 1;
+static int describe_conv_ws(ConvParams p, int ks, int stride, Launch* out, bool grouped = false) {
+  if ((stride != 1 && stride != 2) || (ks != 3 && ks != 1) || p.out_nchw_f32)
+    return fail(UDP_ERR_UNSUPPORTED, "fragment-major weights (wfmt 1): conv ks=%d stride=%d nchw_out=%d has no weight-stationary kernel",
+                ks, stride, p.out_nchw_f32);
   auto knob = [](const char* name, long dflt) {
     const char* v = getenv(name);
     return v ? atol(v) : dflt;
   };
   const int pairs = p.CoutPad / 32;
   const int force_cp = (int)knob("UDP_POSE_WS_CP", 0), force_pb = (int)knob("UDP_POSE_WS_PB", 0);
-  const long min_wgs = knob("UDP_POSE_WS_MINWGS", 512);        // two workgroups on each of the 256 CUs
+  // two workgroups on each of the 256 CUs; a member of a merged launch fills the chip with its siblings
+  const long min_wgs = grouped ? 0 : knob("UDP_POSE_WS_MINWGS", 512);
   // candidates from the fattest wave tile down: the first one that fills the chip wins, else the one with
   // the most workgroups
   WsTile best{}, t{};
@@ -1892,7 +1913,7 @@ static int describe_conv_ws(ConvParams p, int ks, int stride, Launch* out) {
       }
     }
   }
-  if (!have) return 1;
+  if (!have) return fail(UDP_ERR_UNSUPPORTED, "weight-stationary conv: no tile for %dx%d C%d->%d", p.Hout, p.Wout, p.Cin, p.Cout);
   p.G = best.G;
   p.R = best.R;
   p.TW = best.TW;
@@ -1909,8 +1930,17 @@ static int describe_conv_ws(ConvParams p, int ks, int stride, Launch* out) {
   if (getenv("UDP_POSE_DEBUG_TILES"))
     fprintf(stderr, "ws conv k%d s%d %dx%d C%d->%d: G=%d R=%d TW=%d CP=%d PB=%d lds=%zu wgs=%d\n", ks, stride, p.Hout, p.Wout, p.Cin,
             p.Cout, p.G, p.R, p.TW, best.cp, best.pb, best.lds, best.wgs);
-  if (ks == 3) return describe_ws_pb<3, 1, false>(p, best.pb, best.cp, best.lds, out);
-  return describe_ws_pb<1, 1, false>(p, best.pb, best.cp, best.lds, out);
+  int rc = 1;
+  if (ks == 3 && stride == 1) rc = describe_ws_pb<3, 1, false>(p, best.pb, best.cp, best.lds, out);
+  if (ks == 3 && stride == 2) rc = describe_ws_pb<3, 2, false>(p, best.pb, best.cp, best.lds, out);
+  if (ks == 1 && stride == 1) rc = describe_ws_pb<1, 1, false>(p, best.pb, best.cp, best.lds, out);
+  if (ks == 1 && stride == 2) rc = describe_ws_pb<1, 2, false>(p, best.pb, best.cp, best.lds, out);
+  if (rc == 1) return fail(UDP_ERR_UNSUPPORTED, "weight-stationary conv: no kernel for PB=%d CP=%d", best.pb, best.cp);
+  if (rc == UDP_OK && grouped && best.pb == 6 && stride == 1) {
+    out->groupable = 300 + ks * 10 + 6;        // storage/kernel family 3 = split fp16 weight-stationary
+    out->ws_cp = best.cp;
+  }
+  return rc;
 }
 
 // Fills `out` with the kernel, grid and arguments of one fused conv (tile choice included).
@@ -1928,10 +1958,11 @@ int describe_conv(ConvParams p, int dtype, int ks, int stride, Launch* out) {
   if (false ||
       p.N >= 2048)
     return fail(UDP_ERR_UNSUPPORTED, "conv tensor exceeds the 2 GiB the 32-bit buffer offsets cover; split the batch");
-  if (dtype == UDP_F16X2) {
-    const int rc = describe_conv_ws(p, ks, stride, out);
-    if (rc <= 0) return rc;
+  if (p.wfmt == 1) {
+    if (dtype != UDP_F16X2) return fail(UDP_ERR_ARG, "wfmt 1 (fragment-major weights) needs UDP_F16X2");
+    return describe_conv_ws(p, ks, stride, out);
   }
+  if (p.wfmt != 0) return fail(UDP_ERR_ARG, "conv wfmt=%d", p.wfmt);
   int nb = 2;
   const size_t lds = conv_choose_tile(p, ks, stride, dtype, &nb);
   if (p.CoutPad % (nb * 16) != 0)
@@ -1953,7 +1984,12 @@ int describe_conv(ConvParams p, int dtype, int ks, int stride, Launch* out) {
 // into a conv_mfma_multi node): every member uses the instantiation <bf16, 3, 1, NB=2, MBW=4, 4 waves>.
 // Returns 1 when the conv does not qualify (the caller falls back to describe_conv).
 int describe_conv_grouped(ConvParams p, int dtype, int ks, int stride, Launch* out) {
-  if ((dtype != UDP_BF16 && dtype != UDP_F16X2) || (ks != 3 && ks != 1) || stride != 1 || p.out_nchw_f32 || p.nup || p.Cin % 16 || p.Cout % 16 || p.CoutPad % 32) return 1;
+  if (p.wfmt == 1 && dtype == UDP_F16X2 && stride == 1 && (ks == 1 || ks == 3) && !p.out_nchw_f32 && !p.nup) {
+    // member of a conv_ws_multi launch when its tile comes out with 6 pixel blocks per wave (groupable != 0),
+    // a launch of its own otherwise
+    return describe_conv_ws(p, ks, stride, out, true);
+  }
+  if (p.wfmt != 0 || (dtype != UDP_BF16 && dtype != UDP_F16X2) || (ks != 3 && ks != 1) || stride != 1 || p.out_nchw_f32 || p.nup || p.Cin % 16 || p.Cout % 16 || p.CoutPad % 32) return 1;
   const size_t pix_esz = dtype == UDP_BF16 ? 2 : 4;
   if ((size_t)p.N * p.Hin * p.Win * p.in_pitch * pix_esz >= 0x7FFF0000u || (size_t)p.N * p.Hout * p.Wout * p.out_pitch * pix_esz >= 0x7FFF0000u ||
       (p.in_coff * 2) % 16 || (p.in_pitch * 2) % 16 ||
@@ -2000,6 +2036,33 @@ int describe_multi(const Launch* members, int n, ConvMulti* m, Launch* out) {
     attr_set = true;
   }
   if (n < 2 || n > 4) return fail(UDP_ERR_ARG, "describe_multi: %d members", n);
+  if (members[0].groupable / 100 == 3) {       // weight-stationary split-fp16 members
+    static bool ws_attr_set = false;
+    const void* wk[2] = {reinterpret_cast<const void*>(&conv_ws_multi<3>), reinterpret_cast<const void*>(&conv_ws_multi<1>)};
+    if (!ws_attr_set) {
+      for (const void* k : wk) UDP_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      ws_attr_set = true;
+    }
+    memset(m, 0, sizeof(*m));
+    unsigned total = 0, lds = 0;
+    for (int j = 0; j < n; ++j) {
+      if (members[j].groupable != members[0].groupable) return fail(UDP_ERR_ARG, "describe_multi: mixed weight-stationary members");
+      m->p[j] = members[j].p;
+      m->start[j] = total;
+      m->tiles[j] = members[j].grid.x;
+      m->code[j] = members[j].ws_cp;
+      total += members[j].grid.x * members[j].grid.y;
+      if (members[j].lds > lds) lds = members[j].lds;
+    }
+    for (int j = n; j < 5; ++j) m->start[j] = j < 4 ? 0xFFFFFFFFu : total;
+    for (int j = n; j < 4; ++j) m->tiles[j] = 1;
+    out->fn = wk[members[0].groupable / 10 % 10 == 3 ? 0 : 1];
+    out->grid = dim3(total);
+    out->block = dim3(256);
+    out->lds = lds;
+    out->groupable = 0;
+    return UDP_OK;
+  }
   const int h2 = members[0].groupable / 100;
   const int ks = members[0].groupable / 10 % 10;
   int mbw = 3;

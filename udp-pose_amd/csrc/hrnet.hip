@@ -128,8 +128,11 @@ static int validate_op(const udp_hrnet* h, const udp_conv_op& o, int idx) {
     const int pad = o.ks / 2;
     if (o.hout != (o.hin + 2 * pad - o.ks) / o.stride + 1 || o.wout != (o.win + 2 * pad - o.ks) / o.stride + 1)
       return fail(UDP_ERR_ARG, "op %d: output size does not match input/stride", idx);
+    if (o.wfmt != 0 && (o.wfmt != 1 || is_stem || h->dtype != UDP_F16X2))
+      return fail(UDP_ERR_ARG, "op %d: wfmt %d (fragment-major weights need a UDP_F16X2 UDP_OP_CONV)", idx, o.wfmt);
     const size_t wbytes = is_stem ? (size_t)o.ks * o.ks * 3 * o.cout * 4
-                                                : (size_t)o.ks * o.ks * o.cout_pad * o.cin * esize(h->dtype);
+                          : o.wfmt == 1 ? (size_t)o.ks * o.ks * ((o.cin + 31) / 32) * (o.cout_pad / 32) * 4096
+                                        : (size_t)o.ks * o.ks * o.cout_pad * o.cin * esize(h->dtype);
     if (o.w_off < 0 || (size_t)o.w_off + wbytes > h->weights_bytes || (o.w_off & 15))
       return fail(UDP_ERR_ARG, "op %d: weight range outside the blob or misaligned", idx);
     if (o.b_off < 0 || (size_t)o.b_off + (size_t)o.cout_pad * 4 > h->weights_bytes || (o.b_off & 15))
@@ -247,6 +250,7 @@ static int describe_all(const udp_hrnet* h, const float* in, int n, int flip, ch
     p.Cout = o.cout;
     p.CoutPad = o.cout_pad;
     p.relu = o.relu;
+    p.wfmt = o.wfmt;
     p.flip_from = flip ? n : B;
     const bool is_stem = o.kind == UDP_OP_STEM || o.kind == UDP_OP_STEM7;
     p.in_pitch = o.in_pitch ? o.in_pitch : o.cin;
@@ -568,6 +572,7 @@ extern "C" int udp_conv2d_fused(const udp_conv_op* o, int dtype, int n, const vo
   p.Cout = o->cout;
   p.CoutPad = o->cout_pad;
   p.relu = o->relu;
+  p.wfmt = o->wfmt;
   p.flip_from = n;
   p.in_pitch = o->in_pitch ? o->in_pitch : o->cin;
   p.in_coff = o->in_coff;

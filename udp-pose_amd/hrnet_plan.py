@@ -81,6 +81,9 @@ class HRNetProgram:
         self.in_h, self.in_w = in_h, in_w
         self.fuse_blocks = os.environ.get("UDP_POSE_NO_BLOCK_FUSION") is None
         self.group_convs = dtype in ("bf16", "f16x2") and os.environ.get("UDP_POSE_NO_GROUPS") is None
+        # split-fp16 convs on the weight-stationary kernel (fragment-major weights, udp_conv_op.wfmt = 1)
+        # (UDP_POSE_WS=0: the LDS-staged conv_mfma_kernel<H2> instead -- A/B knob)
+        self.use_ws = dtype == "f16x2" and os.environ.get("UDP_POSE_WS", "1") != "0"
         self._groups = 0
         self._tensors = []
         self._ops = []          # dicts with _T references
@@ -111,13 +114,18 @@ class HRNetProgram:
             b = (b - mean) * s + beta
         return w.to(torch.float32), b.to(torch.float32)
 
-    def _pack_conv(self, conv, bn):
+    def _pack_conv(self, conv, bn, ws=False):
         w, b = self._fold(conv, bn)
         cout, cin, kh, kw = w.shape
         cout_pad = _round_up(cout, 32)
         wp = torch.zeros(kh * kw, cout_pad, cin, dtype=torch.float32)
         wp[:, :cout] = w.permute(2, 3, 0, 1).reshape(kh * kw, cout, cin)
-        wbytes = encode_weights(wp, self.dtype)
+        if ws:
+            from .f16x2 import pack_weights_ws
+            encode_weights(wp, self.dtype)                     # range check only
+            wbytes = pack_weights_ws(wp).numpy().tobytes()
+        else:
+            wbytes = encode_weights(wp, self.dtype)
         bp = torch.zeros(cout_pad, dtype=torch.float32)
         bp[:cout] = b
         return self._put(wbytes), self._put(bp.numpy().tobytes()), cout, cin, kh, cout_pad
@@ -129,7 +137,8 @@ class HRNetProgram:
         return t
 
     def _conv(self, x, conv, bn, stride=1, relu=True, res=None, ups=(), to_output=False, group=0):
-        w_off, b_off, cout, cin, ks, cout_pad = self._pack_conv(conv, bn)
+        ws = self.use_ws and not to_output and int(self.sd[conv + ".weight"].shape[2]) in (1, 3) and stride in (1, 2)
+        w_off, b_off, cout, cin, ks, cout_pad = self._pack_conv(conv, bn, ws)
         if cin != x.c:
             raise ValueError("%s: weight expects %d input channels, tensor has %d" % (conv, cin, x.c))
         pad = ks // 2
@@ -138,7 +147,7 @@ class HRNetProgram:
         out = None if to_output else self._new(cout, ho, wo)
         self._ops.append(dict(kind=_lib.UDP_OP_CONV, ks=ks, stride=stride, relu=int(relu), cin=cin, cout=cout,
                               cout_pad=cout_pad, hin=x.h, win=x.w, hout=ho, wout=wo, inp=x, out=out, res=res,
-                              ups=list(ups), w_off=w_off, b_off=b_off, name=conv, group=group))
+                              ups=list(ups), w_off=w_off, b_off=b_off, name=conv, group=group, wfmt=int(ws)))
         return out
 
     def _next_group(self):
@@ -403,7 +412,7 @@ class HRNetProgram:
             o.in_buf = _lib.UDP_BUF_NONE if op["inp"] is None else self._phys[op["inp"].id]
             o.out_buf = _lib.UDP_BUF_OUTPUT if op["out"] is None else self._phys[op["out"].id]
             o.res_buf = _lib.UDP_BUF_NONE if op["res"] is None else self._phys[op["res"].id]
-            for f in ("in_coff", "in_pitch", "out_coff", "out_pitch", "res_coff", "res_pitch", "w2_off", "b2_off", "group"):
+            for f in ("in_coff", "in_pitch", "out_coff", "out_pitch", "res_coff", "res_pitch", "w2_off", "b2_off", "group", "wfmt"):
                 setattr(o, f, op.get(f, 0))
             o.lane = op["lane"]
             o.n_wait = len(op["wait"])
