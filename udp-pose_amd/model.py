@@ -281,6 +281,8 @@ class RSN18Hip(PoseHighResolutionNetHip):
         self.out_channels = int(out_channels)
         self.chl_num = chl_num
         self.dtype = dtype
+        self.psa, self.cfg = False, None
+        self.training, self._trainer, self._stale = False, None, False
         self.device = None
         self.use_graph = True
         self.max_images_per_launch = None     # None: only the 2 GiB-per-tensor limit of one launch applies
@@ -303,6 +305,9 @@ class RSN18Hip(PoseHighResolutionNetHip):
         self._sd = sd
         self._release()
         return self
+
+    def trainer(self):
+        raise NotImplementedError("RSN-18: the training step covers pose_hrnet only")
 
     def _make_program(self, h, w):
         from .rsn_plan import RSNProgram
