@@ -145,7 +145,8 @@ def roofline(net, hp, steps, dtype):
             tc = tj["classes"].get(dom)
             if tc:
                 traffic = round(tc["hbm_bytes_per_launch"], 0)
-    return {"bound": "mfma", "kernel": "conv_mfma_kernel / conv_mfma_multi <%s> %s" % (dtype, dom), "achieved": round(achieved, 2),
+    kname = "conv_ws_multi / conv_ws_h2_kernel (weight-stationary split fp16)" if dtype == "f16x2" else "conv_mfma_kernel / conv_mfma_multi <%s>" % dtype
+    return {"bound": "mfma", "kernel": "%s %s" % (kname, dom), "achieved": round(achieved, 2),
             "peak": round(PEAK_TFLOPS[dtype], 1), "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS[dtype], 4),
             "peak_note": {"f16x2": "algorithmic FLOP/s against the dense fp16 MFMA peak (2.5 PF) / 3 MFMAs per product",
                           "bf16": "dense bf16 MFMA peak", "f32": "fp32 MFMA peak"}[dtype],
