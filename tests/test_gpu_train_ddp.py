@@ -71,7 +71,7 @@ def _worker_w32(rank, world, port, q, backend):
         torch.cuda.synchronize()
         p = tr.flat[:tr._n_param]
         q.put((rank, bool(torch.isfinite(p).all()), float(p.double().sum()), float((p.double() ** 2).sum()),
-               p[::997].cpu().numpy(), float(loss.cpu()[0])))
+               p[::997].cpu().numpy(), float(loss.cpu()[0]), list(tr.reduce_order), len(tr._buckets)))
     finally:
         dist.destroy_process_group()
 
@@ -96,6 +96,11 @@ def test_two_rank_w32_config3_size_replicas_stay_identical():
     assert res[0][2] == res[1][2] and res[0][3] == res[1][3]
     np.testing.assert_array_equal(res[0][4], res[1][4])
     assert np.isfinite(res[0][5]) and np.isfinite(res[1][5])
+    # the exchange is overlapped with the backward: every ~25 MB bucket is all-reduced exactly once, issued as soon
+    # as its last gradient is written -- the bucket of the LAST layers first, the stem's bucket last
+    order, nb = res[0][6], res[0][7]
+    assert nb >= 4 and sorted(order) == list(range(nb)) and order == res[1][6]
+    assert order[0] == nb - 1 and order[-1] == 0, order
 
 
 def test_two_rank_train_step_equals_summed_shard_gradients():

@@ -56,6 +56,14 @@ def allreduce_sum_(flat_grads, bucket_elems=6 * 1024 * 1024, group=None):
     return works
 
 
+def allreduce_sum_async(bucket, group=None):
+    """SUM all-reduce of one gradient bucket, not waited for: the returned work handle's ``wait()`` orders the
+    caller's stream after it.  torch.distributed enqueues the collective on its own stream behind everything
+    already queued on the current stream, so it may be issued right after the kernels that wrote the bucket and
+    runs concurrently with the kernels issued afterwards (the rest of the backward)."""
+    return dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+
 def allreduce_mean_(flat_grads, bucket_elems=6 * 1024 * 1024, group=None):
     """In-place mean over ranks of a flat gradient buffer, in buckets (xGMI is point-to-point:
     ~25 MB fp32 buckets keep every link busy and let later buckets overlap remaining backward work).

@@ -99,6 +99,20 @@ class HRNetTrainer:
         self._bn_ws = torch.zeros(_lib.lib().udp_bn_workspace_doubles(1024), dtype=torch.float64, device=self.device)
         self._loss = torch.zeros(2, dtype=torch.float64, device=self.device)
         self._tape = []
+        # gradient buckets for the all-reduce (~25 MB each): consecutive parameters of the flat
+        # gradient; a bucket is reduced as soon as the backward has written its last gradient, so the exchange
+        # of the late layers' gradients runs under the backward of the early ones (DDP's overlap, which the
+        # reference gets from RSN/exps/RSN18.coco/train.py:46-48 / nn.DataParallel's reducer)
+        self.bucket_elems = 6 * 1024 * 1024
+        self._buckets, self._bucket_of = [], {}
+        lo, cnt = 0, 0
+        for i, k in enumerate(self._keys):
+            self._bucket_of[k] = len(self._buckets)
+            cnt += 1
+            end = self._off[self._keys[i + 1]] if i + 1 < len(self._keys) else self._n_param
+            if end - lo >= self.bucket_elems or i + 1 == len(self._keys):
+                self._buckets.append((lo, end, cnt))
+                lo, cnt = end, 0
 
     # ------------------------------------------------------------------ parameter views
     def _p(self, key):
@@ -194,7 +208,7 @@ class HRNetTrainer:
             _lib.check(L.udp_conv2d_fused(C.byref(dop), self._dt, x.n, src.data_ptr(), wd.data_ptr(),
                                           self._zeros.data_ptr(), None if res is None else res.data_ptr(), None, None,
                                           None, x.grad.data_ptr(), self._stream()))
-        self._tape.append((y, backward, y_keep))
+        self._tape.append((y, backward, y_keep, [name + ".weight"] + ([bias_key] if bias_key else [])))
         return y
 
     def _bn(self, x, name, relu=True, res=None):
@@ -226,7 +240,7 @@ class HRNetTrainer:
                 else:
                     _lib.check(L.udp_ew_accumulate(res.grad.data_ptr(), g_out.data_ptr(), res.n, res.h, res.w, res.ck,
                                                    0, 0, 0, self._dt, self._stream()))
-        self._tape.append((y, backward, save))
+        self._tape.append((y, backward, save, [name + ".weight", name + ".bias"]))
         return y
 
     def _sum_relu(self, terms):
@@ -254,7 +268,7 @@ class HRNetTrainer:
                 else:
                     _lib.check(L.udp_upsample_bwd(g.data_ptr(), y.n, y.h, y.w, y.ck, s, t.grad.data_ptr(), int(have),
                                                   self._dt, self._stream()))
-        self._tape.append((y, backward, None))
+        self._tape.append((y, backward, None, []))
         return y
 
     # ------------------------------------------------------------------ the HRNet graph (pose_hrnet.py)
@@ -334,19 +348,42 @@ class HRNetTrainer:
         self._out = self._conv(ys[0], "final_layer", bias_key="final_layer.bias", nchw_out=True)
         return self._out.buf
 
-    def backward(self, dheat):
+    def backward(self, dheat, world_size=1):
         """dheat: fp32 [N,C,h,w] = d loss / d heat-maps.  Fills self.grad (zero_grad is implicit: every
-        parameter gradient is overwritten)."""
+        parameter gradient is overwritten).  ``world_size > 1``: every gradient bucket is SUM-all-reduced
+        (asynchronously, on the communication stream of torch.distributed) as soon as its last gradient has been
+        written, overlapping the rest of the backward; on return all buckets are reduced."""
         L = _lib.lib()
         o = self._out
         g = torch.empty(o.n * o.h * o.w * o.ck, dtype=self._tdt, device=self.device)
         _lib.check(L.udp_nchw_to_nhwc(dheat.data_ptr(), o.n, o.c, o.h, o.w, o.ck, g.data_ptr(), self._dt, self._stream()))
         o.grad = g
-        for y, bwd, _ in reversed(self._tape):
+        left = [c for _, _, c in self._buckets]
+        works = []
+        self.reduce_order = []                # bucket indices in the order their all-reduce was issued
+        for y, bwd, _, keys in reversed(self._tape):
             if y.grad is not None:
                 bwd()
+                if world_size > 1:
+                    for k in keys:
+                        b = self._bucket_of[k]
+                        left[b] -= 1
+                        if left[b] == 0:
+                            works.append(self._reduce_bucket(b))
             y.grad = None
         self._tape = []
+        if world_size > 1:
+            for b, n_left in enumerate(left):          # a bucket with an unused parameter: its gradient stays as is
+                if n_left > 0:
+                    works.append(self._reduce_bucket(b))
+            for w in works:
+                w.wait()
+
+    def _reduce_bucket(self, b):
+        from .dist import allreduce_sum_async
+        lo, hi, _ = self._buckets[b]
+        self.reduce_order.append(b)
+        return allreduce_sum_async(self.grad[lo:hi])
 
     def loss_and_grad(self, heat, target, target_weight):
         """criterion(output, target, target_weight) (loss.py:15-76) and its gradient w.r.t. output."""
@@ -372,9 +409,6 @@ class HRNetTrainer:
         """function.py:46-76 for one batch.  Returns the loss tensor fp64 [2] = (L_hm, L_offset) on device."""
         heat = self.forward(x)
         loss, d = self.loss_and_grad(heat, target.contiguous(), target_weight.contiguous())
-        self.backward(d)
-        if world_size > 1:
-            from .dist import allreduce_sum_
-            allreduce_sum_(self.grad)                      # the one exchange step (SURVEY 8e); mean = grad_scale
-        self.adam_step(1.0 / world_size)
+        self.backward(d, world_size)                       # incl. the one exchange step (SURVEY 8e), bucket by bucket
+        self.adam_step(1.0 / world_size)                   # mean over ranks = grad_scale
         return loss
