@@ -1854,36 +1854,54 @@ struct WsTile {
 static bool ws_tile(const ConvParams& p, int ks, int stride, int cp, int pb, WsTile* t) {
   const int pg = 4 / cp;
   const int maxM = 16 * pb * pg;
-  int TW = p.Wout;
-  while (TW > 64 || TW > maxM) TW = (TW + 1) / 2;
-  int maxR = maxM / TW;
-  if (maxR > p.Hout) maxR = p.Hout;
-  int R = largest_divisor_leq(p.Hout, maxR);
-  if (R * 2 <= maxR) R = maxR;
-  int G = 1;
-  if (R == p.Hout && TW == p.Wout) {
-    G = maxM / (R * TW);
-    if (G > p.N) G = p.N;
-    if (G < 1) G = 1;
+  // column split: the full width, or 2..4 equal column tiles -- whichever fills the wave's pixel blocks best
+  // (a 72-column map tiles exactly as 3 x 24 columns x 4 rows = 6 blocks, but only as 9 of 12 block slots at 36)
+  bool have = false;
+  double best_util = 0.0;
+  for (int split = 1; split <= 4 || !have; ++split) {
+    if (split > 8) break;
+    const int TW = ceil_div(p.Wout, split);
+    if (TW > 64 || TW > maxM || (have && TW < 8)) continue;
+    int maxR = maxM / TW;
+    if (maxR > p.Hout) maxR = p.Hout;
+    int R = largest_divisor_leq(p.Hout, maxR);
+    if (R * 2 <= maxR) R = maxR;
+    int G = 1;
+    if (R == p.Hout && TW == p.Wout) {
+      G = maxM / (R * TW);
+      if (G > p.N) G = p.N;
+      if (G < 1) G = 1;
+    }
+    auto npix = [&](int g, int r) { return g * ((r - 1) * stride + ks) * ((TW - 1) * stride + ks); };
+    while (npix(G, R) > MAXG * 64 && G > 1) --G;
+    while (npix(G, R) > MAXG * 64 && R > 1) R = (R + 1) / 2;
+    if (npix(G, R) > MAXG * 64) continue;
+    const int nstage = ceil_div(p.Cin, 32) > 1 ? 2 : 1;                         // stage buffers x (hi, lo) images
+    const size_t lds = (size_t)((npix(G, R) + 15) / 16) * 16 * ROWB * 2 * nstage;
+    if (lds > 160 * 1024) continue;
+    // pixel blocks per wave the tile really needs (the halo limit may have shrunk it): the smallest instantiated
+    // count that covers them, so no wave idles under masked blocks
+    const int need = ceil_div(ceil_div(G * R * TW, 16), pg);
+    if (need > pb) continue;
+    const int pbe = need <= 2 ? 2 : need <= 3 ? 3 : need <= 4 ? 4 : 6;
+    const int tiles = ceil_div(p.N, G) * ceil_div(p.Hout, R) * ceil_div(p.Wout, TW);
+    // score = useful pixels / pixel slots over the whole layer (ragged last tiles and masked blocks are waste)
+    //         x the share of the staged halo tile that is not halo (narrow tiles stage more of it)
+    const double util = (double)p.N * p.Hout * p.Wout / ((double)tiles * 16 * pbe * pg) *
+                        ((double)G * R * TW * stride * stride / (double)npix(G, R));
+    if (!have || util > best_util + 0.05) {
+      have = true;
+      best_util = util;
+      t->cp = cp;
+      t->pb = pbe;
+      t->G = G;
+      t->R = R;
+      t->TW = TW;
+      t->lds = lds;
+      t->wgs = tiles * (p.CoutPad / (cp * 32));
+    }
   }
-  auto npix = [&](int g, int r) { return g * ((r - 1) * stride + ks) * ((TW - 1) * stride + ks); };
-  while (npix(G, R) > MAXG * 64 && G > 1) --G;
-  while (npix(G, R) > MAXG * 64 && R > 1) R = (R + 1) / 2;
-  if (npix(G, R) > MAXG * 64) return false;
-  const int nstage = ceil_div(p.Cin, 32) > 1 ? 2 : 1;
-  t->lds = (size_t)((npix(G, R) + 15) / 16) * 16 * ROWB * 2 * nstage;
-  if (t->lds > 160 * 1024) return false;
-  // pixel blocks per wave the tile really needs (the halo limit may have shrunk it): the smallest instantiated
-  // count that covers them, so no wave idles under masked blocks
-  const int need = ceil_div(ceil_div(G * R * TW, 16), pg);
-  if (need > pb) return false;
-  t->cp = cp;
-  t->pb = need <= 2 ? 2 : need <= 3 ? 3 : need <= 4 ? 4 : 6;
-  t->G = G;
-  t->R = R;
-  t->TW = TW;
-  t->wgs = ceil_div(p.N, G) * ceil_div(p.Hout, R) * ceil_div(p.Wout, TW) * (p.CoutPad / (cp * 32));
-  return true;
+  return have;
 }
 
 static int describe_conv_ws(ConvParams p, int ks, int stride, Launch* out, bool grouped = false) {
