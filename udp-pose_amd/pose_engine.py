@@ -99,7 +99,7 @@ class UdpPsaPoseHip:
 
     SKELETONS = SKELETONS
 
-    def __init__(self, model_path, config_path, device="cuda", dtype="f32", state_dict=None, config=None):
+    def __init__(self, model_path, config_path, device="cuda", dtype="f16x2", state_dict=None, config=None):
         self.config = config if config is not None else load_config(config_path)
         self.input_shape = list(self.config.MODEL.IMAGE_SIZE)          # [w, h]
         ds = str(self.config.DATASET.DATASET).lower()
@@ -161,8 +161,13 @@ class UdpPsaPoseHip:
         post = bool(self.config.TEST.POST_PROCESS) and not offset
         preds, maxvals, _, _ = decode_device(hm, center, scale, self.config.MODEL.TARGET_TYPE, post,
                                              float(self.config.LOSS.KPD), cs_is_f32=True, want_idx=False)
-        kp = preds.cpu().numpy()
-        return (kp if post else kp.astype(np.float32)), maxvals.cpu().numpy()
+        kp, mv = preds.cpu().numpy(), maxvals.cpu().numpy()
+        if not np.isfinite(mv).all():
+            # split-fp16 storage turns an activation beyond fp16's range (|x| >= 65520) into NaN -- surfaced here
+            # instead of returning garbage keypoints (the fp32 mode has the range of the reference)
+            raise FloatingPointError("non-finite heat-maps (dtype=%s): an activation left the storage type's range; "
+                                     "run the engine with dtype='f32'" % self.model.dtype)
+        return (kp if post else kp.astype(np.float32)), mv
 
     def draw_keypoints(self, image, keypoints, radius=1):
         """pose_engine.py:65-67: marks keypoints (filled squares) and skeleton end points in place."""
