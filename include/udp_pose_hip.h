@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UDP_POSE_ABI_VERSION 13
+#define UDP_POSE_ABI_VERSION 14
 
 enum udp_status {
   UDP_OK = 0,
@@ -155,6 +155,14 @@ double udp_hrnet_flops_per_image(const udp_hrnet* h);
 int udp_conv2d_fused(const udp_conv_op* op_host, int dtype, int n, const void* in, const void* weights,
                      const float* bias, const void* res, const void* up0, const void* up1,
                      const void* up2, void* out, void* stream);
+/* Training form of a plain conv (fp32 / bf16 NHWC, no addends, no ReLU): additionally leaves the statistics
+ * pass of the BatchNorm2d that follows it (pose_hrnet.py:46, :83 ...: `bn(conv(x))` in train mode) in `bn_ws`:
+ * one row of 2*cout doubles per workgroup tile -- sum x and sum x*x of the output AS STORED -- summed in the
+ * conv epilogue instead of a separate pass over the tensor.  *bn_rows receives the row count
+ * (<= udp_bn_rows_max()); feed both to udp_bn_train_fwd_from_sums. */
+int udp_conv2d_fused_bn(const udp_conv_op* op_host, int dtype, int n, const void* in, const void* weights,
+                        const float* bias, void* out, double* bn_ws, size_t bn_ws_doubles, int* bn_rows,
+                        void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Flip-test fuse.  Replaces flip_back / flip_back_offset
@@ -293,6 +301,13 @@ int udp_bn_train_fwd(const void* x, int64_t m, int c, const float* gamma, const 
                      float momentum, float* running_mean, float* running_var, float* save_mean,
                      float* save_invstd, const void* res, int relu, void* y, int dtype, double* ws,
                      void* stream);
+/* The same with the statistics pass already done: `ws` holds `rows` partial rows of 2*c doubles
+ * ([row][0..c) = sum x, [row][c..2c) = sum x*x), as udp_conv2d_fused_bn leaves them.  rows <= udp_bn_rows_max(). */
+int udp_bn_rows_max(void);
+int udp_bn_train_fwd_from_sums(const void* x, int64_t m, int c, const float* gamma, const float* beta, float eps,
+                               float momentum, float* running_mean, float* running_var, float* save_mean,
+                               float* save_invstd, const void* res, int relu, void* y, int dtype, double* ws,
+                               int rows, void* stream);
 /* Backward of the above.  g = dy * (y_relu > 0) when y_relu != NULL (the ReLU that followed), else dy.
  * dgamma = sum g*xhat, dbeta = sum g, dx = gamma*invstd*(g - dbeta/m - xhat*dgamma/m);
  * g_out (optional) receives g -- the gradient of the residual input. */

@@ -49,6 +49,21 @@ if world > 1:
     dist.barrier()
     dist.destroy_process_group()
 if rank == 0:
+    import json
+    from udp_pose_amd.hrnet_plan import HRNetProgram
+    macs = HRNetProgram(sd, synth.W32_EXTRA, 256, 192, "f32").macs_per_image()
+    flops = 3 * 2.0 * macs * a.batch                     # forward + input gradient + weight gradient
+    peak = {"f32": 157.3, "bf16": 2500.0}[a.dtype]
+    tf = flops / (dev * 1e-3) / 1e12
+    print(json.dumps({"metric": "images/sec HRNet-W32 256x192 training step (fwd + JointsMSELoss + bwd + Adam"
+                                + (" + gradient all-reduce)" if world > 1 else ")"),
+                      "value": round(a.batch * world / wall * 1e3, 1), "unit": "images/s", "n_gpus": world,
+                      "ms_per_step": round(wall, 3), "dtype": a.dtype, "batch_per_gpu": a.batch,
+                      "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
+                                   "frac": round(tf / peak, 4),
+                                   "note": "algorithmic FLOPs of the three conv passes per step / device time of the "
+                                           "whole step; the step is bound by its many small BatchNorm / element-wise "
+                                           "launches, not by the matrix pipe (profiles/r02_train_*_kernel_stats)"}}))
     print("world %d (global batch %d): %.0f img/s" % (world, a.batch * world, a.batch * world / wall * 1e3))
     print("train W32 b=%d/GPU %s: %.1f ms/step (device %.1f ms), %.0f img/s per GPU, loss %s, peak mem %.1f GiB" % (
         a.batch, a.dtype, wall, dev, a.batch / wall * 1e3, loss.cpu().numpy(), torch.cuda.max_memory_allocated() / 2**30))

@@ -58,6 +58,7 @@ struct ConvParams {
   int flip_from;         // stem only: images >= flip_from read image (n - flip_from) mirrored in x
   int sbuf;              // conv_mfma_kernel: one stage buffer instead of two (set by conv_choose_tile)
   int wfmt;              // udp_conv_op.wfmt: 1 = fragment-major split-fp16 weights (conv_ws_h2_kernel)
+  double* bn_ws;         // training: per-workgroup BatchNorm partial sums of the output, [tile][2*Cout] (or null)
 };
 
 // Kernel argument of conv_mfma_multi: up to 4 independent convs in one launch (flat block index ->

@@ -554,6 +554,14 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int ti
   }
 
   UDP_STAMP(5);
+  // BatchNorm statistics of the output (training, p.bn_ws): per-lane sums of x and x*x over its pixels, of the
+  // values AS STORED (rounded to T) -- what the normalisation pass will read
+  // (fp64 like the separate statistics pass: var = E[x^2] - mean^2 cancels for channels with |mean| >> std)
+  double bsum[NB][4], bsq[NB][4];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bsum[nb][q] = bsq[nb][q] = 0.0;
   // ---- epilogue (acc = conv + bias): lane holds couts cbase .. cbase + 4*NB - 1 of pixel i
 #pragma unroll
   for (int i = 0; i < MBW; ++i) {
@@ -597,6 +605,53 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int ti
           for (int q = 0; q < 4; ++q) v[nb][q] = v[nb][q] > 0.f ? v[nb][q] : 0.f;
       }
       store_vec_buf<T, NB>(r_out, ooff, out_lo, v);
+      if constexpr (!std::is_same<T, H2>::value) {
+        if (p.bn_ws && opix[i] >= 0) {
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const double x = (double)(float)(T)v[nb][q];
+              bsum[nb][q] += x;
+              bsq[nb][q] += x * x;
+            }
+        }
+      }
+    }
+  }
+  if constexpr (!NCHW && !std::is_same<T, H2>::value) {
+    if (p.bn_ws) {   // workgroup-uniform
+      // lanes li = 0..15 of a kg group hold different pixels of the same 4*NB channels: butterfly over li, then
+      // the NW waves through LDS (all stage buffers are free now), then ONE fp64 row per workgroup:
+      // bn_ws[tile][0..C) = sum x, [C..2C) = sum x*x -- summed later in a fixed order (deterministic)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) {
+            bsum[nb][q] += __shfl_xor(bsum[nb][q], o, 64);
+            bsq[nb][q] += __shfl_xor(bsq[nb][q], o, 64);
+          }
+      __syncthreads();                                   // every wave has left the MFMA loop: smem is free
+      double* red = reinterpret_cast<double*>(smem);    // [wave][2][BN]
+      if (li == 0) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            red[(wave * 2 + 0) * BN + 4 * NB * kg + 4 * nb + q] = bsum[nb][q];
+            red[(wave * 2 + 1) * BN + 4 * NB * kg + 4 * nb + q] = bsq[nb][q];
+          }
+      }
+      __syncthreads();
+      if (tid < 2 * BN) {
+        const int which = tid / BN, ch = tid - which * BN;
+        double a = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) a += red[(w * 2 + which) * BN + ch];
+        if (cb * BN + ch < p.Cout) p.bn_ws[(size_t)tile_id * 2 * p.Cout + which * p.Cout + cb * BN + ch] = a;
+      }
     }
   }
   UDP_STAMP(6);
@@ -1747,7 +1802,7 @@ static int describe_persist_mbw(const ConvParams& p, int mbw, size_t lds, int gr
 // Persistent single-chunk form (bf16, Cin = 32): returns 1 when it does not apply.
 static int describe_persist(const ConvParams& p, int ks, int stride, int nb, int mbw, Launch* out) {
   const int npix = p.G * p.IH * p.IW;
-  if (p.out_nchw_f32 || p.Cin != 32 || npix > MAXGP * 64 || p.ntiles >= 65536) return 1;
+  if (p.out_nchw_f32 || p.Cin != 32 || npix > MAXGP * 64 || p.ntiles >= 65536 || p.bn_ws) return 1;
   if (p.in_pitch != p.Cin || p.in_coff || p.out_pitch != p.Cout || p.out_coff || (p.res && (p.res_pitch != p.Cout || p.res_coff)))
     return 1;                                         // channel-slice views: generic kernel
   const size_t lds = (size_t)(ks * ks * nb * 16 + 2 * ((npix + 15) / 16) * 16) * ROWB;

@@ -544,9 +544,29 @@ extern "C" int udp_hrnet_destroy(udp_hrnet* h) {
   return UDP_OK;
 }
 
+static int conv2d_fused_impl(const udp_conv_op* o, int dtype, int n, const void* in, const void* weights,
+                             const float* bias, const void* res, const void* up0, const void* up1,
+                             const void* up2, void* out, double* bn_ws, size_t bn_ws_doubles, int* bn_rows, void* stream);
+
 extern "C" int udp_conv2d_fused(const udp_conv_op* o, int dtype, int n, const void* in, const void* weights,
                                 const float* bias, const void* res, const void* up0, const void* up1,
                                 const void* up2, void* out, void* stream) {
+  return conv2d_fused_impl(o, dtype, n, in, weights, bias, res, up0, up1, up2, out, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int udp_conv2d_fused_bn(const udp_conv_op* o, int dtype, int n, const void* in, const void* weights,
+                                   const float* bias, void* out, double* bn_ws, size_t bn_ws_doubles, int* bn_rows,
+                                   void* stream) {
+  if (!bn_ws || !bn_rows) return fail(UDP_ERR_ARG, "udp_conv2d_fused_bn: null pointer");
+  if (dtype == UDP_F16X2 || !o || o->kind != UDP_OP_CONV || o->out_buf == UDP_BUF_OUTPUT || o->n_up || o->relu ||
+      (o->out_pitch && o->out_pitch != o->cout) || o->out_coff)
+    return fail(UDP_ERR_UNSUPPORTED, "udp_conv2d_fused_bn: a plain fp32 / bf16 NHWC conv without addends, ReLU or channel views");
+  return conv2d_fused_impl(o, dtype, n, in, weights, bias, nullptr, nullptr, nullptr, nullptr, out, bn_ws, bn_ws_doubles, bn_rows, stream);
+}
+
+static int conv2d_fused_impl(const udp_conv_op* o, int dtype, int n, const void* in, const void* weights,
+                             const float* bias, const void* res, const void* up0, const void* up1,
+                             const void* up2, void* out, double* bn_ws, size_t bn_ws_doubles, int* bn_rows, void* stream) {
   if (!o || !in || !out) return fail(UDP_ERR_ARG, "udp_conv2d_fused: null pointer");
   if (dtype != UDP_F32 && dtype != UDP_BF16 && dtype != UDP_F16X2) return fail(UDP_ERR_ARG, "udp_conv2d_fused: dtype %d", dtype);
   if (n <= 0) return fail(UDP_ERR_ARG, "udp_conv2d_fused: n=%d", n);
@@ -596,7 +616,14 @@ extern "C" int udp_conv2d_fused(const udp_conv_op* o, int dtype, int n, const vo
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   Launch l;
+  p.bn_ws = bn_ws;
   const int rc = o->kind == UDP_OP_FUSE ? describe_fuse(p, dtype, &l) : describe_conv(p, dtype, o->ks, o->stride, &l);
   if (rc) return rc;
+  if (bn_ws) {
+    // one partial row of 2*Cout doubles per tile (grid.x); the caller's workspace must hold them
+    if ((size_t)l.grid.x * 2 * o->cout > bn_ws_doubles)
+      return fail(UDP_ERR_WORKSPACE, "udp_conv2d_fused_bn: %u partial rows x %d doubles exceed the workspace", l.grid.x, 2 * o->cout);
+    *bn_rows = (int)l.grid.x;
+  }
   return run_launch(l, s);
 }

@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 //   MODE 0: (x, x*x)                       forward statistics
 //   MODE 1: (g, g*xhat), g = dy*(y>0)      backward sums
 // Thread = 4 consecutive channels (16-byte loads) x one row lane; C % 4 == 0.
-constexpr int kBnMaxBlocks = 512;
+constexpr int kBnMaxBlocks = 4096;   // partial rows: the sums kernel uses <= 512, a conv epilogue one per tile
 
 typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
 
@@ -813,6 +813,25 @@ extern "C" int udp_bn_train_fwd(const void* x, int64_t m, int c, const float* ga
                  (bn_apply_kernel<float><<<nblocks(total4, 256 * 2), 256, 0, s>>>((const float*)x, (const float*)res, save_mean, save_invstd, gamma, beta, total4, c, relu, (float*)y)),
                  (bn_apply_kernel<__bf16><<<nblocks(total4, 256 * 2), 256, 0, s>>>((const __bf16*)x, (const __bf16*)res, save_mean, save_invstd, gamma, beta, total4, c, relu, (__bf16*)y)));
   return launched("udp_bn_train_fwd");
+}
+
+extern "C" int udp_bn_rows_max(void) { return kBnMaxBlocks; }
+
+extern "C" int udp_bn_train_fwd_from_sums(const void* x, int64_t m, int c, const float* gamma, const float* beta, float eps,
+                                          float momentum, float* running_mean, float* running_var, float* save_mean,
+                                          float* save_invstd, const void* res, int relu, void* y, int dtype, double* ws,
+                                          int rows, void* stream) {
+  if (!x || !gamma || !beta || !save_mean || !save_invstd || !y || !ws) return fail(UDP_ERR_ARG, "udp_bn_train_fwd_from_sums: null pointer");
+  if (m <= 0 || c <= 0 || (c & 3)) return fail(UDP_ERR_ARG, "udp_bn_train_fwd_from_sums: m=%lld c=%d (c must be a multiple of 4)", (long long)m, c);
+  if (rows <= 0 || rows > kBnMaxBlocks) return fail(UDP_ERR_ARG, "udp_bn_train_fwd_from_sums: %d partial rows (1..%d)", rows, kBnMaxBlocks);
+  if (check_dtype(dtype, "udp_bn_train_fwd_from_sums")) return UDP_ERR_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  bn_fwd_finalize_kernel<<<(c + 3) / 4, 256, 0, s>>>(ws, rows, m, c, eps, momentum, running_mean, running_var, save_mean, save_invstd);
+  const long total4 = m * c / 4;
+  UDP_DISPATCH_T(dtype,
+                 (bn_apply_kernel<float><<<nblocks(total4, 256 * 2), 256, 0, s>>>((const float*)x, (const float*)res, save_mean, save_invstd, gamma, beta, total4, c, relu, (float*)y)),
+                 (bn_apply_kernel<__bf16><<<nblocks(total4, 256 * 2), 256, 0, s>>>((const __bf16*)x, (const __bf16*)res, save_mean, save_invstd, gamma, beta, total4, c, relu, (__bf16*)y)));
+  return launched("udp_bn_train_fwd_from_sums");
 }
 
 extern "C" int udp_bn_train_bwd(const void* x, const void* dy, const void* y_relu, int64_t m, int c, const float* gamma,

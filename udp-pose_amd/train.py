@@ -32,12 +32,13 @@ def _is_param(k):
 
 class _Act:
     """An NHWC activation [n,h,w,ck] (ck = channels rounded up to 16) and its gradient."""
-    __slots__ = ("buf", "n", "h", "w", "c", "ck", "grad", "needs_grad")
+    __slots__ = ("buf", "n", "h", "w", "c", "ck", "grad", "needs_grad", "bn_rows")
 
     def __init__(self, buf, n, h, w, c, ck, needs_grad=True):
         self.buf, self.n, self.h, self.w, self.c, self.ck = buf, n, h, w, c, ck
         self.grad = None
         self.needs_grad = needs_grad
+        self.bn_rows = 0            # > 0: the conv that produced it left that many BatchNorm partial rows in _bn_ws
 
 
 class HRNetTrainer:
@@ -99,6 +100,8 @@ class HRNetTrainer:
         self._bn_ws = torch.zeros(_lib.lib().udp_bn_workspace_doubles(1024), dtype=torch.float64, device=self.device)
         self._loss = torch.zeros(2, dtype=torch.float64, device=self.device)
         self._tape = []
+        import os
+        self.fuse_bn_stats = os.environ.get("UDP_POSE_NO_BN_FUSION") is None     # A/B knob
         # gradient buckets for the all-reduce (~25 MB each): consecutive parameters of the flat
         # gradient; a bucket is reduced as soon as the backward has written its last gradient, so the exchange
         # of the late layers' gradients runs under the backward of the early ones (DDP's overlap, which the
@@ -161,7 +164,7 @@ class HRNetTrainer:
         op.out_buf = _lib.UDP_BUF_OUTPUT if nchw else 0
         return op
 
-    def _conv(self, x, name, stride=1, bias_key=None, nchw_out=False):
+    def _conv(self, x, name, stride=1, bias_key=None, nchw_out=False, bn_stats=False):
         L = _lib.lib()
         cout, cin, ks, wf, wd = self._convs[name]
         if x.c != cin:
@@ -183,8 +186,21 @@ class HRNetTrainer:
             y_keep = b
         else:
             y_keep = None
-        _lib.check(L.udp_conv2d_fused(C.byref(op), self._dt, x.n, x.buf.data_ptr(), wf.data_ptr(), bias, None, None,
-                                      None, None, y.buf.data_ptr(), self._stream()))
+        if bn_stats and self.fuse_bn_stats and not nchw_out and y.c == y.ck:
+            # the BatchNorm that follows reads its statistics from the conv epilogue's partial sums
+            rows = C.c_int(0)
+            rc = L.udp_conv2d_fused_bn(C.byref(op), self._dt, x.n, x.buf.data_ptr(), wf.data_ptr(), bias,
+                                       y.buf.data_ptr(), self._bn_ws.data_ptr(), self._bn_ws.numel(), C.byref(rows),
+                                       self._stream())
+            if rc == -4:       # UDP_ERR_WORKSPACE: more tiles than partial rows fit -> separate statistics pass
+                _lib.check(L.udp_conv2d_fused(C.byref(op), self._dt, x.n, x.buf.data_ptr(), wf.data_ptr(), bias, None,
+                                              None, None, None, y.buf.data_ptr(), self._stream()))
+            else:
+                _lib.check(rc)
+                y.bn_rows = rows.value
+        else:
+            _lib.check(L.udp_conv2d_fused(C.byref(op), self._dt, x.n, x.buf.data_ptr(), wf.data_ptr(), bias, None, None,
+                                          None, None, y.buf.data_ptr(), self._stream()))
 
         def backward():
             dy = y.grad                                   # NHWC [n,ho,wo,ck(cout)]
@@ -218,11 +234,13 @@ class HRNetTrainer:
             raise ValueError("%s: BatchNorm over %d channels (not a multiple of 16)" % (name, x.c))
         y = self._new(x.n, x.h, x.w, x.c)
         save = torch.empty(2 * c, dtype=torch.float32, device=self.device)
-        _lib.check(L.udp_bn_train_fwd(x.buf.data_ptr(), m, c, self._p(name + ".weight"), self._p(name + ".bias"),
-                                      BN_EPS, BN_MOMENTUM, self._p(name + ".running_mean"),
-                                      self._p(name + ".running_var"), save.data_ptr(), save.data_ptr() + 4 * c,
-                                      None if res is None else res.buf.data_ptr(), int(relu), y.buf.data_ptr(),
-                                      self._dt, self._bn_ws.data_ptr(), self._stream()))
+        args = (x.buf.data_ptr(), m, c, self._p(name + ".weight"), self._p(name + ".bias"), BN_EPS, BN_MOMENTUM,
+                self._p(name + ".running_mean"), self._p(name + ".running_var"), save.data_ptr(), save.data_ptr() + 4 * c,
+                None if res is None else res.buf.data_ptr(), int(relu), y.buf.data_ptr(), self._dt, self._bn_ws.data_ptr())
+        if x.bn_rows:
+            _lib.check(L.udp_bn_train_fwd_from_sums(*args, x.bn_rows, self._stream()))
+        else:
+            _lib.check(L.udp_bn_train_fwd(*args, self._stream()))
 
         def backward():
             x.grad = self._like(x)
@@ -273,16 +291,16 @@ class HRNetTrainer:
 
     # ------------------------------------------------------------------ the HRNet graph (pose_hrnet.py)
     def _basic(self, x, p):
-        t = self._bn(self._conv(x, p + ".conv1"), p + ".bn1")
-        return self._bn(self._conv(t, p + ".conv2"), p + ".bn2", res=x)
+        t = self._bn(self._conv(x, p + ".conv1", bn_stats=True), p + ".bn1")
+        return self._bn(self._conv(t, p + ".conv2", bn_stats=True), p + ".bn2", res=x)
 
     def _bottleneck(self, x, p):
-        a = self._bn(self._conv(x, p + ".conv1"), p + ".bn1")
-        b = self._bn(self._conv(a, p + ".conv2"), p + ".bn2")
+        a = self._bn(self._conv(x, p + ".conv1", bn_stats=True), p + ".bn1")
+        b = self._bn(self._conv(a, p + ".conv2", bn_stats=True), p + ".bn2")
         r = x
         if (p + ".downsample.0") in self._convs:
-            r = self._bn(self._conv(x, p + ".downsample.0"), p + ".downsample.1", relu=False)
-        return self._bn(self._conv(b, p + ".conv3"), p + ".bn3", res=r)
+            r = self._bn(self._conv(x, p + ".downsample.0", bn_stats=True), p + ".downsample.1", relu=False)
+        return self._bn(self._conv(b, p + ".conv3", bn_stats=True), p + ".bn3", res=r)
 
     def _module(self, xs, p, num_blocks, last):
         nb = len(xs)
@@ -296,13 +314,13 @@ class HRNetTrainer:
             for j in range(nb):
                 q = "%s.fuse_layers.%d.%d" % (p, i, j)
                 if j > i:
-                    terms.append((self._bn(self._conv(xs[j], q + ".0"), q + ".1", relu=False), j - i))
+                    terms.append((self._bn(self._conv(xs[j], q + ".0", bn_stats=True), q + ".1", relu=False), j - i))
                 elif j == i:
                     terms.append((self._conv(xs[j], q + ".0") if last else xs[j], 0))
                 else:
                     t = xs[j]
                     for k in range(i - j):
-                        t = self._bn(self._conv(t, "%s.%d.0" % (q, k), stride=2), "%s.%d.1" % (q, k),
+                        t = self._bn(self._conv(t, "%s.%d.0" % (q, k), stride=2, bn_stats=True), "%s.%d.1" % (q, k),
                                      relu=(k != i - j - 1))
                     terms.append((t, 0))
             outs.append(self._sum_relu(terms))
@@ -313,11 +331,11 @@ class HRNetTrainer:
         for i in range(n_cur):
             q = "%s.%d" % (name, i)
             if i < len(ys):
-                xs.append(self._bn(self._conv(ys[i], q + ".0"), q + ".1") if (q + ".0") in self._convs else ys[i])
+                xs.append(self._bn(self._conv(ys[i], q + ".0", bn_stats=True), q + ".1") if (q + ".0") in self._convs else ys[i])
             else:
                 y = ys[-1]
                 for k in range(i + 1 - len(ys)):
-                    y = self._bn(self._conv(y, "%s.%d.0" % (q, k), stride=2), "%s.%d.1" % (q, k))
+                    y = self._bn(self._conv(y, "%s.%d.0" % (q, k), stride=2, bn_stats=True), "%s.%d.1" % (q, k))
                 xs.append(y)
         return xs
 
@@ -333,8 +351,8 @@ class HRNetTrainer:
         _lib.check(L.udp_pack_conv_weights_batch(self._pack_table.data_ptr(), len(self._convs), self._dt, self._stream()))
         a = self._new(n, h, w, 3, needs_grad=False)
         _lib.check(L.udp_nchw_to_nhwc(x.data_ptr(), n, 3, h, w, a.ck, a.buf.data_ptr(), self._dt, self._stream()))
-        a = self._bn(self._conv(a, "conv1", stride=2), "bn1")
-        a = self._bn(self._conv(a, "conv2", stride=2), "bn2")
+        a = self._bn(self._conv(a, "conv1", stride=2, bn_stats=True), "bn1")
+        a = self._bn(self._conv(a, "conv2", stride=2, bn_stats=True), "bn2")
         for k in range(4):
             a = self._bottleneck(a, "layer1.%d" % k)
         ys = [a]
