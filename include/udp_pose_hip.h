@@ -234,6 +234,9 @@ int udp_target_offset(const float* joints, const float* vis, int n, int j, int i
  * (deep_hrnet/lib/core/loss.py:15-39 / :41-76).  pred, target: fp32 [b,c,hw];
  * weight fp32 [b,j].  loss_out: fp64 [2] = (L_hm, L_offset) (L_offset = 0 for the
  * plain loss); grad: fp32 like pred (d(L_hm+L_offset)/d pred), may be NULL.
+ * The two scalars are accumulated with fp64 atomic adds of per-workgroup partial sums, so
+ * their last bits may differ from run to run (~1e-16 relative); the gradient is computed per
+ * element and does not depend on them.
  * ------------------------------------------------------------------------- */
 int udp_mse_loss(const float* pred, const float* target, const float* weight, int b, int j, int hw,
                  int is_offset, double* loss_out, float* grad, void* stream);
