@@ -186,3 +186,30 @@ def test_bench_gpus_n_launches_its_own_ranks():
     if not torch.cuda.is_available():
         assert r.returncode != 0
         assert (r.stdout + r.stderr).count("bench.py needs a GPU") == 2
+
+
+def test_f16x2_host_encoding_and_fragment_major_weights():
+    """Split-fp16 host helpers (udp-pose_amd/f16x2.py): hi + lo * 2^-11 keeps 22 significant bits over fp16's
+    normal range (and degrades gracefully below it); pack_weights_ws puts w[tap][cout][cin] where
+    include/udp_pose_hip.h (udp_conv_op.wfmt = 1) says the weight-stationary kernel reads it."""
+    import torch
+    from udp_pose_amd import f16x2
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(4096, generator=g) * torch.logspace(-4, 4, 4096)
+    x[0], x[1] = 0.0, -0.0
+    r = f16x2.decode(f16x2.encode(x[None, :]))[0]
+    rel = ((r - x).abs() / x.abs().clamp_min(1e-30))[x.abs() > 2.0 ** -14]
+    assert float(rel.max()) <= 2.0 ** -21                      # <= 2^-22 plus the fp32 arithmetic of this check
+    assert float((r - x).abs()[x.abs() <= 2.0 ** -14].max()) <= 2.0 ** -34
+    # fragment-major layout: 3x3, 40 real couts padded to 64, 48 cin padded to 64
+    taps, cout_pad, cin = 9, 64, 48
+    w = torch.randn(taps, cout_pad, cin, generator=g) * 0.05
+    packed = f16x2.pack_weights_ws(w).view(torch.float16).reshape(taps, 2, 2, 2, 2, 64, 8)   # tap, chunk, pair, nb, plane, lane, j
+    enc = f16x2.encode(torch.nn.functional.pad(w, (0, 16)))     # [tap, cout, plane, k]
+    rng = np.random.default_rng(1)
+    for _ in range(200):
+        tap, c, pair, nb, plane, lane, j = (int(rng.integers(n)) for n in (taps, 2, 2, 2, 2, 64, 8))
+        li, kg = lane & 15, lane >> 4
+        cout = 32 * pair + 8 * (li >> 2) + 4 * nb + (li & 3)
+        assert packed[tap, c, pair, nb, plane, lane, j] == enc[tap, cout, plane, 32 * c + 8 * kg + j]
+    assert packed.numel() * 2 == taps * 2 * 2 * 4096

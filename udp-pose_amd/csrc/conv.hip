@@ -762,6 +762,9 @@ __device__ __forceinline__ void conv_ws_body(const ConvParams& p, const int tile
     }
   };
 
+  UDP_STAMP(1);
+  stage(0, smem);      // chunk 0 is on its way while the rest of the per-lane state is set up
+
   // ---- the lane's PB output pixels
   int prow[PB], opix[PB], ocrd[PB];
   const int cwave = (cby * CP + cp) * 32;   // first cout of the wave's pair of blocks
@@ -815,8 +818,6 @@ __device__ __forceinline__ void conv_ws_body(const ConvParams& p, const int tile
       }
   }
 
-  UDP_STAMP(1);
-  stage(0, smem);
   load_a(0, ah[0], al[0]);
   load_a(nsteps > 1 ? 1 : 0, ah[1], al[1]);
   if constexpr (!NCHW) {
