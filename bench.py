@@ -115,9 +115,18 @@ def roofline(net, hp, steps, dtype):
     esz = 2 if dtype == "bf16" else 4
     b = 2 * hp.n
     classes = {}
-    for t, (name, kind, ks, stride, cin, cout, ho, wo) in zip(ms, desc):
+    # ops of one launch group run as ONE merged launch (conv_ws_multi / conv_mfma_multi): they form a class of
+    # their own whose launch count is the number of groups, so `avg_launch_us` is the kernel's launch duration
+    # that rocprofv3 --kernel-trace --stats reports (udp_hrnet_profile splits a merged launch's time over its
+    # members, summed back here)
+    groups = [int(o.group) for o in net.program(hp.h, hp.w).ops_array()]
+    merged_ids = {}
+    for t, (name, kind, ks, stride, cin, cout, ho, wo), gid in zip(ms, desc, groups):
         key = {0: "stem", 2: "fuse_sum", 3: "stem7x7", 4: "maxpool", 5: "bilinear", 10: "basic_block_c32"}.get(
             kind, "conv%dx%d_s%d_nb%d" % (ks, ks, stride, 4 if cout % 64 == 0 else 2))
+        if gid and kind == 1:
+            key = "merged_conv%dx%d_s%d" % (ks, ks, stride)
+            merged_ids.setdefault(key, set()).add(gid)
         flops = 2.0 * ks * ks * cin * cout * ho * wo * b if kind in (0, 1, 3) else 0.0
         if kind == 10:                                   # fused BasicBlock: two 3x3 convs
             flops = 2 * 2.0 * 9 * cin * cout * ho * wo * b
@@ -128,6 +137,8 @@ def roofline(net, hp, steps, dtype):
         c[1] += flops
         c[2] += byts
         c[3] += 1
+    for key, ids in merged_ids.items():
+        classes[key][3] = len(ids)
     dom = max(classes, key=lambda k: classes[k][0])
     t_ms, flops, byts, cnt = classes[dom]
     achieved = flops / (t_ms * 1e-3) / 1e12
@@ -142,11 +153,21 @@ def roofline(net, hp, steps, dtype):
         with open(tfile) as f:
             tj = json.load(f)
         if tj.get("lib_sha256") == lib_sha256():
-            tc = tj["classes"].get(dom)
-            if tc:
-                traffic = round(tc["hbm_bytes_per_launch"], 0)
-    kname = "conv_ws_multi / conv_ws_h2_kernel (weight-stationary split fp16)" if dtype == "f16x2" else "conv_mfma_kernel / conv_mfma_multi <%s>" % dtype
-    return {"bound": "mfma", "kernel": "%s %s" % (kname, dom), "achieved": round(achieved, 2),
+            if dom == "merged_conv3x3_s1":       # the per-op PMC run has the members as 3x3 stride-1 classes
+                tot = sum(tc["fetch_bytes"] + tc["write_bytes"] for k, tc in tj["classes"].items() if k.startswith("conv3x3_s1"))
+                ops = sum(tc["launches"] for k, tc in tj["classes"].items() if k.startswith("conv3x3_s1"))
+                n_dom = sum(1 for (_, kind, ks, st, *_), g in zip(desc, groups) if g and kind == 1 and ks == 3 and st == 1)
+                traffic = round(tot * n_dom / ops / cnt, 0)
+            else:
+                tc = tj["classes"].get(dom)
+                if tc:
+                    traffic = round(tc["hbm_bytes_per_launch"], 0)
+    if dom.startswith("merged_"):
+        kname = ("conv_ws_multi<%s> (merged weight-stationary split-fp16 convs of one HRNet depth)" % dom[11]) if dtype == "f16x2" \
+            else "conv_mfma_multi<%s>" % dtype
+    else:
+        kname = "conv_ws_h2_kernel" if dtype == "f16x2" else "conv_mfma_kernel<%s>" % dtype
+    return {"bound": "mfma", "kernel": "%s: class %s" % (kname, dom), "achieved": round(achieved, 2),
             "peak": round(PEAK_TFLOPS[dtype], 1), "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS[dtype], 4),
             "peak_note": {"f16x2": "algorithmic FLOP/s against the dense fp16 MFMA peak (2.5 PF) / 3 MFMAs per product",
                           "bf16": "dense bf16 MFMA peak", "f32": "fp32 MFMA peak"}[dtype],
