@@ -1500,6 +1500,136 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const ConvParams p) {
   }
 }
 
+// Stem convs on the matrix pipe, general form: KS x KS stride-2 conv on the NCHW fp32 network input as a GEMM with
+// K = KS*KS*3 (27 -> one 32-deep k-step; 147 -> five: the RSN 7x7 stem, network.py:125-137), for bf16 and for
+// split-fp16 output.  The weight fragments (fragment-major: [k-step][cout block][plane][lane][8]) are built once
+// per workgroup in LDS from the fp32 [ky][kx][ci][64] weights; a lane gathers the 8 K values of its pixel straight
+// from the input (neighbouring pixels share cache lines) and splits each into hi + lo (bf16: the input keeps ~16
+// bits through two MFMAs on bf16 weights; H2: three fp16 MFMAs on hi/lo weights, as everywhere in that mode).
+template <typename T, int KS>
+__global__ __launch_bounds__(256) void stem_mfma_k(const ConvParams p) {
+  constexpr bool SPLIT = std::is_same<T, H2>::value;
+  constexpr int K = KS * KS * 3, NS = (K + 31) / 32, PAD = KS / 2, WPL = SPLIT ? 2 : 1;
+  using E = typename std::conditional<SPLIT, _Float16, __bf16>::type;
+  using Frag = typename std::conditional<SPLIT, f16x8, bf16x8>::type;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  E* wl = reinterpret_cast<E*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kg = lane >> 4;
+  const float* wg = reinterpret_cast<const float*>(p.wgt);
+  for (int e = tid; e < NS * 4 * WPL * 512; e += 256) {
+    const int j = e & 7, ln = (e >> 3) & 63, pl = (e >> 9) % WPL, nb = ((e >> 9) / WPL) & 3, st = (e >> 9) / (WPL * 4);
+    const int k = 32 * st + 8 * (ln >> 4) + j;
+    const int cout = 16 * ((ln & 15) >> 2) + 4 * nb + (ln & 3);       // row ln&15 of tile nb (lane-owns-16-couts permutation)
+    const float w = k < K ? wg[k * 64 + cout] : 0.f;
+    if constexpr (SPLIT) {
+      const _Float16 hi = (_Float16)w;
+      wl[e] = pl == 0 ? hi : (_Float16)((w - (float)hi) * kLoScale);
+    } else {
+      wl[e] = (__bf16)w;
+    }
+  }
+  __syncthreads();
+  const int cbase = 16 * kg;
+  f32x4 bias[4];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) bias[nb] = *reinterpret_cast<const f32x4*>(p.bias + cbase + 4 * nb);
+  unsigned koff[NS][4];            // per k-step the lane's 8 K values as 16-bit (ky | kx << 4 | ch << 8), 0xFFFF = padding
+#pragma unroll
+  for (int st = 0; st < NS; ++st)
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      unsigned v = 0;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int k = 32 * st + 8 * kg + 2 * h + q, tap = k / 3;
+        const unsigned c = k < K ? (unsigned)((tap / KS) | ((tap % KS) << 4) | ((k % 3) << 8)) : 0xFFFFu;
+        v |= c << (16 * q);
+      }
+      koff[st][h] = v;
+    }
+  const long total = (long)p.N * p.Hout * p.Wout;
+  const long ntile = (total + 15) / 16;
+  const size_t plane = (size_t)p.Hin * p.Win;
+  for (long tile = (long)blockIdx.x * 4 + wave; tile < ntile; tile += (long)gridDim.x * 4) {
+    const long pix = tile * 16 + li;
+    const bool okp = pix < total;
+    const long pp = okp ? pix : total - 1;
+    const int xo = pp % p.Wout;
+    const long t2 = pp / p.Wout;
+    const int yo = t2 % p.Hout;
+    const int n = t2 / p.Hout;
+    const bool mirror = n >= p.flip_from;
+    const float* in = reinterpret_cast<const float*>(p.in) + (size_t)(mirror ? n - p.flip_from : n) * 3 * plane;
+    f32x4 acc[4], accx[SPLIT ? 4 : 1];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) acc[nb] = bias[nb];
+#pragma unroll
+    for (int nb = 0; nb < (SPLIT ? 4 : 1); ++nb) accx[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      Frag hi, lo;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned ko = (koff[st][j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+        const int gy = yo * 2 - PAD + (int)(ko & 15u), gx = xo * 2 - PAD + (int)((ko >> 4) & 15u);
+        const bool ok = ko != 0xFFFFu && gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win;
+        const int sx = mirror ? p.Win - 1 - gx : gx;
+        const float v = ok ? in[(size_t)(ko >> 8) * plane + (size_t)gy * p.Win + sx] : 0.f;
+        hi[j] = (E)v;
+        lo[j] = (E)((v - (float)hi[j]) * (SPLIT ? kLoScale : 1.f));
+      }
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        const Frag wh = *reinterpret_cast<const Frag*>(wl + ((st * 4 + nb) * WPL) * 512 + lane * 8);
+        if constexpr (SPLIT) {
+          const Frag wlo = *reinterpret_cast<const Frag*>(wl + ((st * 4 + nb) * WPL + 1) * 512 + lane * 8);
+          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, hi, acc[nb], 0, 0, 0);
+          accx[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, lo, accx[nb], 0, 0, 0);
+          accx[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, hi, accx[nb], 0, 0, 0);
+        } else {
+          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, hi, acc[nb], 0, 0, 0);
+          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, lo, acc[nb], 0, 0, 0);
+        }
+      }
+    }
+    if constexpr (SPLIT) {
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) acc[nb] += accx[nb] * kLoInv;
+    }
+    if (p.relu) {
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[nb][q] = acc[nb][q] > 0.f ? acc[nb][q] : 0.f;
+    }
+    if (okp) {
+      if constexpr (SPLIT) {
+        unsigned char* o = reinterpret_cast<unsigned char*>(p.out) + (size_t)pix * 256 + cbase * 2;   // 64 hi + 64 lo fp16 per pixel
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          f16x8 oh, ol;
+          h2_split8(acc[2 * h], acc[2 * h + 1], oh, ol);
+          *reinterpret_cast<f16x8*>(o + 16 * h) = oh;
+          *reinterpret_cast<f16x8*>(o + 128 + 16 * h) = ol;
+        }
+      } else {
+        __bf16* o = reinterpret_cast<__bf16*>(p.out) + (size_t)pix * 64 + cbase;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          bf16x8 ov;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            ov[q] = (__bf16)acc[2 * h][q];
+            ov[4 + q] = (__bf16)acc[2 * h + 1][q];
+          }
+          *reinterpret_cast<bf16x8*>(o + 8 * h) = ov;
+        }
+      }
+    }
+  }
+}
+
 // Exchange-unit output for the highest-resolution branch when it has no conv
 // term: out = relu(x_i + sum_k nearest_up(T_ik)), pose_hrnet.py:267-272 with the
 // identity f_ii of :222-223.
@@ -2176,6 +2306,15 @@ int describe_stem(const ConvParams& p, int dtype, Launch* out) {
     out->p = p;
     return UDP_OK;
   }
+  if (dtype == UDP_F16X2 && getenv("UDP_POSE_STEM_VALU") == nullptr) {
+    const long ntile = (total + 15) / 16;
+    out->fn = reinterpret_cast<const void*>(&stem_mfma_k<H2, 3>);
+    out->grid = dim3((unsigned)((ntile + 3) / 4 < 2048 ? (ntile + 3) / 4 : 2048));
+    out->block = dim3(256);
+    out->lds = 1 * 4 * 2 * 1024;
+    out->p = p;
+    return UDP_OK;
+  }
   out->fn = dtype == UDP_F32     ? reinterpret_cast<const void*>(&stem_conv_kernel<float>)
             : dtype == UDP_F16X2 ? reinterpret_cast<const void*>(&stem_conv_kernel<H2>)
                                  : reinterpret_cast<const void*>(&stem_conv_kernel<__bf16>);
@@ -2234,6 +2373,24 @@ int describe_bilinear(const ConvParams& p, int dtype, Launch* out) {
 int describe_stem7(const ConvParams& p, int dtype, Launch* out) {
   if (p.Cout != 64) return fail(UDP_ERR_UNSUPPORTED, "7x7 stem expects 64 output channels, got %d", p.Cout);
   const long total = (long)p.N * p.Hout * p.Wout;
+  if (dtype != UDP_F32 && getenv("UDP_POSE_STEM_VALU") == nullptr) {
+    // bf16 / split fp16: the 7x7 stem as a K = 147 -> 160 GEMM on the matrix pipe
+    static bool attr_set = false;
+    const void* kb = reinterpret_cast<const void*>(&stem_mfma_k<__bf16, 7>);
+    const void* kh = reinterpret_cast<const void*>(&stem_mfma_k<H2, 7>);
+    if (!attr_set) {
+      UDP_HIP_CHECK(hipFuncSetAttribute(kb, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      UDP_HIP_CHECK(hipFuncSetAttribute(kh, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      attr_set = true;
+    }
+    const long ntile = (total + 15) / 16;
+    out->fn = dtype == UDP_F16X2 ? kh : kb;
+    out->grid = dim3((unsigned)((ntile + 3) / 4 < 1024 ? (ntile + 3) / 4 : 1024));
+    out->block = dim3(256);
+    out->lds = 5 * 4 * (dtype == UDP_F16X2 ? 2 : 1) * 1024;
+    out->p = p;
+    return UDP_OK;
+  }
   out->fn = dtype == UDP_F32     ? reinterpret_cast<const void*>(&stem7_conv_kernel<float>)
             : dtype == UDP_F16X2 ? reinterpret_cast<const void*>(&stem7_conv_kernel<H2>)
                                  : reinterpret_cast<const void*>(&stem7_conv_kernel<__bf16>);
