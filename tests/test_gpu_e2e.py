@@ -195,7 +195,10 @@ def test_w32_batch64_properties(w32_gaussian, dtype):
 
 
 def test_w32_bf16_mode_accuracy(golden_dir, w32_gaussian):
-    """Throughput mode (bf16 storage, fp32 accumulate): documented, looser gate."""
+    """bf16 storage (fp32 accumulate) is REDUCED PRECISION and not a parity mode: this is a sanity bound on what it
+    does to the (noise-like) reference heat-maps, far outside the 1e-3 / arg-max contract that the fp32 and
+    split-fp16 modes hold (test_w32_f16x2_matches_reference_heatmaps); bounds on trained maps:
+    test_trained_peaked_maps_bf16_storage_bound."""
     sd, _ = w32_gaussian
     g = np.load(os.path.join(golden_dir, "hrnet_w32_gaussian.npz"))
     net = MODELS["pose_hrnet"](_cfg(synth.W32_EXTRA, 17, "gaussian"), is_train=False, dtype="bf16")
