@@ -481,3 +481,35 @@ def test_trained_peaked_maps_bf16_storage_bound(golden_dir):
     assert np.abs(hm - g["fused"]).max() < 0.02
     assert (d == 0).mean() >= 0.9 and (d <= 1).mean() >= 0.95
     assert np.percentile(px, 95) < 0.05
+
+
+def test_engine_buckets_the_box_count_and_bounds_its_caches(golden_dir, w32_gaussian):
+    """a frame's box count changes every call.  The engine runs the network at a bucketed batch size
+    (1, 2, 4, 8, multiples of 8; padding rows repeat the last box and are dropped), so three boxes give exactly
+    the keypoints of the same three boxes inside a call with five; the model keeps at most MAX_IO_SHAPES buffer
+    sets (least recently used evicted) and the library at most 8 graphs, however many distinct counts arrive."""
+    from udp_pose_amd.config import default_config
+    from udp_pose_amd.pose_engine import UdpPsaPoseHip
+    sd, _ = w32_gaussian
+    cfg = default_config()
+    cfg.MODEL.EXTRA = synth.W32_EXTRA
+    cfg.MODEL.IMAGE_SIZE = [192, 256]
+    cfg.MODEL.HEATMAP_SIZE = [48, 64]
+    cfg.DATASET.DATASET = "coco"
+    cfg.TEST.POST_PROCESS = True
+    eng = UdpPsaPoseHip("synthetic", None, "cuda", state_dict=sd, config=cfg)
+    assert [eng._bucket(n) for n in (1, 2, 3, 4, 5, 8, 9, 16, 17)] == [1, 2, 4, 4, 8, 8, 16, 16, 24]
+    frame = synth.synth_frame_u8(480, 640, seed=12)
+    boxes = synth.synth_boxes(5, seed=6)
+    kp5, mv5 = eng.infer_pose(frame, boxes)
+    kp3, mv3 = eng.infer_pose(frame, boxes[:3])
+    np.testing.assert_array_equal(kp3, kp5[:3])
+    np.testing.assert_array_equal(mv3, mv5[:3])
+    kpf, _ = eng.infer_pose(frame, boxes[:3], flip_test=True)
+    assert kpf.shape == (3, 17, 2) and np.isfinite(kpf).all()
+    for n in (1, 2, 9, 17, 25, 33, 41, 49, 57, 65):        # ten more buckets than the caches hold
+        kp, _ = eng.infer_pose(frame, synth.synth_boxes(n, seed=n))
+        assert kp.shape == (n, 17, 2) and np.isfinite(kp).all()
+    assert len(eng.model._io) <= eng.model.MAX_IO_SHAPES
+    kp3b, _ = eng.infer_pose(frame, boxes[:3])               # evicted and rebuilt: same answer
+    np.testing.assert_array_equal(kp3b, kp3)
