@@ -18,7 +18,7 @@ def rows(d, counter):
     f = (glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"))[0]
     out = []
     for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] == counter and any(k in r["Kernel_Name"] for k in ("conv_mfma_", "conv_ws_", "basic_block_c32", "stem_conv_kernel", "stem_mfma_kernel", "fuse_sum_kernel")):
+        if r["Counter_Name"] == counter and any(k in r["Kernel_Name"] for k in ("conv_mfma_", "conv_ws_", "basic_block_c32", "stem_conv_kernel", "stem_mfma_k", "fuse_sum_kernel")):
             out.append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
     out.sort()
     return [v for _, v in out]
