@@ -263,6 +263,63 @@ def test_train_two_steps_match_reference_fixture(golden_dir, tt):
     np.testing.assert_allclose(got, ref, rtol=0, atol=1e-3 * max(1.0, np.abs(ref).max()))
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("ks,stride,cin,cout,h,w,n", [(3, 1, 32, 32, 64, 48, 3), (3, 2, 64, 128, 32, 24, 2), (1, 1, 64, 256, 16, 12, 5),
+                                                      (3, 1, 256, 256, 8, 6, 7), (3, 2, 16, 64, 64, 48, 2)])
+def test_conv_epilogue_batchnorm_statistics(ks, stride, cin, cout, h, w, n, dtype):
+    """udp_conv2d_fused_bn: the conv output equals udp_conv2d_fused's bit for bit, and the partial rows it leaves
+    (one per workgroup tile: sum x, sum x*x of the output AS STORED, fp64) add up to the statistics of that
+    output; udp_bn_train_fwd_from_sums then normalises exactly like the separate statistics pass."""
+    L = _lib.lib()
+    dt = _lib.DTYPES[dtype]
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    g = torch.Generator().manual_seed(ks + cin + cout)
+    x = (torch.randn(n, h, w, cin, generator=g) + 0.5).to(tdt).cuda()
+    wt = torch.randn(cout, cin, ks, ks, generator=g).cuda() / np.sqrt(cin * ks * ks)
+    esz = 2 if dtype == "bf16" else 4
+    wf = torch.empty(ks * ks * _rup(cout, 32) * cin * esz, dtype=torch.uint8, device="cuda")
+    _lib.check(L.udp_pack_conv_weights(wt.data_ptr(), cout, cin, ks, dt, wf.data_ptr(), None, _stream()))
+    pad = ks // 2
+    ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
+    op = _lib.ConvOp()
+    op.kind, op.ks, op.stride, op.relu = _lib.UDP_OP_CONV, ks, stride, 0
+    op.cin, op.cout, op.cout_pad = cin, cout, _rup(cout, 32)
+    op.hin, op.win, op.hout, op.wout = h, w, ho, wo
+    op.in_buf = op.res_buf = _lib.UDP_BUF_NONE
+    zeros = torch.zeros(op.cout_pad, device="cuda")
+    y0 = torch.empty(n, ho, wo, cout, dtype=tdt, device="cuda")
+    y1 = torch.empty_like(y0)
+    _lib.check(L.udp_conv2d_fused(C.byref(op), dt, n, x.data_ptr(), wf.data_ptr(), zeros.data_ptr(), None, None, None, None,
+                                  y0.data_ptr(), _stream()))
+    ws = torch.full((L.udp_bn_workspace_doubles(cout),), float("nan"), dtype=torch.float64, device="cuda")
+    rows = C.c_int(0)
+    _lib.check(L.udp_conv2d_fused_bn(C.byref(op), dt, n, x.data_ptr(), wf.data_ptr(), zeros.data_ptr(), y1.data_ptr(),
+                                     ws.data_ptr(), ws.numel(), C.byref(rows), _stream()))
+    assert torch.equal(y0, y1) and 0 < rows.value <= L.udp_bn_rows_max()
+    part = ws[:rows.value * 2 * cout].view(rows.value, 2, cout).sum(0).cpu().numpy()
+    yd = y1.double().reshape(-1, cout)
+    np.testing.assert_allclose(part[0], yd.sum(0).cpu().numpy(), rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(part[1], (yd * yd).sum(0).cpu().numpy(), rtol=1e-12, atol=1e-9)
+    # normalisation from the partial rows == normalisation with its own statistics pass
+    m = n * ho * wo
+    gamma, beta = torch.rand(cout, device="cuda") + 0.5, torch.randn(cout, device="cuda")
+    outs = []
+    for fused in (True, False):
+        rm, rv = torch.zeros(cout, device="cuda"), torch.ones(cout, device="cuda")
+        save = torch.empty(2 * cout, device="cuda")
+        out = torch.empty_like(y1)
+        args = (y1.data_ptr(), m, cout, gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1, rm.data_ptr(), rv.data_ptr(),
+                save.data_ptr(), save.data_ptr() + 4 * cout, None, 1, out.data_ptr(), dt)
+        if fused:
+            _lib.check(L.udp_bn_train_fwd_from_sums(*args, ws.data_ptr(), rows.value, _stream()))
+        else:
+            ws2 = torch.zeros(L.udp_bn_workspace_doubles(cout), dtype=torch.float64, device="cuda")
+            _lib.check(L.udp_bn_train_fwd(*args, ws2.data_ptr(), _stream()))
+        outs.append((out.float().cpu(), rm.cpu(), rv.cpu(), save.cpu()))
+    for a, b in zip(outs[0], outs[1]):
+        torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-6)
+
+
 def test_w32_train_step_at_config3_size(golden_dir):
     """BASELINE config 3 at its own per-GPU size: pose_hrnet_w32 256x192, JointsMSELoss, 32 images.  One
     train_step (fp32) against the CPU oracle's train-mode forward + criterion + autograd (oracle/train.py =
