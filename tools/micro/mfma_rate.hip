@@ -1,5 +1,5 @@
 // MFMA issue-rate probe (gfx950): cycles per v_mfma_f32_16x16x32_f16 for accumulator dependency patterns.
-//   hipcc --offload-arch=gfx950 -O3 tools/micro/mfma_rate.hip -o /tmp/mfma_rate && /tmp/mfma_rate
+//   hipcc --offload-arch=gfx950 -O3 -w tools/micro/mfma_rate.hip -o tools/micro/mfma_rate && tools/micro/mfma_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
