@@ -66,6 +66,12 @@ def test_psa_mini_matches_reference_fixture(golden_dir):
     both = net.raw_forward(x, flip_test=True).clone()
     mirrored = net(torch.flip(x, dims=[3])).clone()
     torch.testing.assert_close(both[2:], mirrored, rtol=0, atol=1e-5)
+    # split-fp16 storage: the same north-star gate as fp32 (the attention ops read / write hi + lo pairs)
+    nh = MODELS["pose_hrnet_psa"](_cfg(extra, 17, "gaussian"), is_train=False, dtype="f16x2").load_state_dict(sd).to("cuda")
+    gh = nh(x).clone().cpu().numpy()
+    print("psa mini f16x2 max abs err %.3g" % np.abs(gh - g["out"]).max())
+    np.testing.assert_allclose(gh, g["out"], rtol=0, atol=1e-3)
+    np.testing.assert_array_equal(gh.reshape(2, 17, -1).argmax(2), g["out"].reshape(2, 17, -1).argmax(2))
     # bf16 storage: sanity only (attention softmax amplifies rounding; gate = fraction of the signal)
     nb = MODELS["pose_hrnet_psa"](_cfg(extra, 17, "gaussian"), is_train=False, dtype="bf16").load_state_dict(sd).to("cuda")
     gb = nb(x).clone().cpu().numpy()

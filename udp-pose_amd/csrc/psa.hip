@@ -20,9 +20,31 @@ namespace udp {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Split-fp16 storage (UDP_F16X2, csrc/conv.hip): per pixel the C hi values, then the C lo values (fp16),
+// x = hi + lo * 2^-11.
+struct H2 {};
+constexpr float kLoScale = 2048.f, kLoInv = 1.f / 2048.f;
+
+// channel c of pixel px of a [pixels][C] map stored as T
 template <typename T>
-__device__ __forceinline__ float ldf(const T* p) {
-  return (float)*p;
+__device__ __forceinline__ float ldx(const void* base, size_t px, int C, int c) {
+  if constexpr (std::is_same<T, H2>::value) {
+    const _Float16* q = reinterpret_cast<const _Float16*>(base) + px * 2 * C + c;
+    return (float)q[0] + (float)q[C] * kLoInv;
+  } else {
+    return (float)reinterpret_cast<const T*>(base)[px * C + c];
+  }
+}
+template <typename T>
+__device__ __forceinline__ void stx(void* base, size_t px, int C, int c, float v) {
+  if constexpr (std::is_same<T, H2>::value) {
+    _Float16* q = reinterpret_cast<_Float16*>(base) + px * 2 * C + c;
+    const _Float16 hi = (_Float16)v;
+    q[0] = hi;
+    q[C] = (_Float16)((v - (float)hi) * kLoScale);
+  } else {
+    reinterpret_cast<T*>(base)[px * C + c] = (T)v;
+  }
 }
 
 __device__ __forceinline__ float block_reduce(float v, bool is_max, float* red) {
@@ -62,14 +84,14 @@ __global__ __launch_bounds__(256) void psa_pool_kernel(const ConvParams p) {
   __shared__ float red[4];
   const int C = p.Cin, HW = p.Hin * p.Win;
   const int n = blockIdx.x;
-  const T* x = reinterpret_cast<const T*>(p.in) + (size_t)n * HW * C;
+  const size_t px0 = (size_t)n * HW;
   const PsaW w(reinterpret_cast<const float*>(p.wgt), C);
   float* e = sm;
   float* part = sm + HW;
   float lmax = -INFINITY;
   for (int px = threadIdx.x; px < HW; px += 256) {
     float q = 0.f;
-    for (int c = 0; c < C; ++c) q = fmaf(ldf(x + (size_t)px * C + c), w.wq[c], q);
+    for (int c = 0; c < C; ++c) q = fmaf(ldx<T>(p.in, px0 + px, C, c), w.wq[c], q);
     e[px] = q;
     lmax = fmaxf(lmax, q);
   }
@@ -85,7 +107,7 @@ __global__ __launch_bounds__(256) void psa_pool_kernel(const ConvParams p) {
   const int c = threadIdx.x % C, grp = threadIdx.x / C, ngrp = 256 / C;
   float a = 0.f, m = 0.f;
   for (int px = grp; px < HW; px += ngrp) {
-    const float v = ldf(x + (size_t)px * C + c);
+    const float v = ldx<T>(p.in, px0 + px, C, c);
     a = fmaf(e[px], v, a);
     m += v;
   }
@@ -166,7 +188,8 @@ __global__ __launch_bounds__(256) void psa_scale_kernel(const ConvParams p) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int c = i % C;
     const long n = i / ((long)HW * C);
-    reinterpret_cast<T*>(p.out)[i] = (T)(ldf(reinterpret_cast<const T*>(p.in) + i) * mask[n * p.res_pitch + c]);
+    const size_t px = (size_t)(i / C);
+    stx<T>(p.out, px, C, c, ldx<T>(p.in, px, C, c) * mask[n * p.res_pitch + c]);
   }
 }
 
@@ -176,7 +199,7 @@ __global__ __launch_bounds__(256) void psa_sp_kernel(const ConvParams p) {
   extern __shared__ float sm[];   // msp[HW] | part[256] | M[C2] | S[C2] | g[C2]
   const int C = p.Cout, C2 = p.Cin, HW = p.Hin * p.Win;
   const int n = blockIdx.x, t = threadIdx.x;
-  const T* th = reinterpret_cast<const T*>(p.in) + (size_t)n * HW * C2;
+  const size_t px0 = (size_t)n * HW;
   float* msp = sm;
   float* part = sm + HW;
   float* M = part + 256;
@@ -184,7 +207,7 @@ __global__ __launch_bounds__(256) void psa_sp_kernel(const ConvParams p) {
   float* g = S + C2;
   const int j = t % C2, grp = t / C2, ngrp = 256 / C2;
   float lm = -INFINITY;
-  for (int px = grp; px < HW; px += ngrp) lm = fmaxf(lm, ldf(th + (size_t)px * C2 + j));
+  for (int px = grp; px < HW; px += ngrp) lm = fmaxf(lm, ldx<T>(p.in, px0 + px, C2, j));
   part[t] = lm;
   __syncthreads();
   if (t < C2) {
@@ -195,7 +218,7 @@ __global__ __launch_bounds__(256) void psa_sp_kernel(const ConvParams p) {
   }
   __syncthreads();
   float ls = 0.f;
-  for (int px = grp; px < HW; px += ngrp) ls += expf(ldf(th + (size_t)px * C2 + j) - M[j]);
+  for (int px = grp; px < HW; px += ngrp) ls += expf(ldx<T>(p.in, px0 + px, C2, j) - M[j]);
   part[t] = ls;
   __syncthreads();
   if (t < C2) {
@@ -206,13 +229,11 @@ __global__ __launch_bounds__(256) void psa_sp_kernel(const ConvParams p) {
   __syncthreads();
   for (int px = t; px < HW; px += 256) {
     float ctx = 0.f;
-    for (int k = 0; k < C2; ++k) ctx = fmaf(g[k], expf(ldf(th + (size_t)px * C2 + k) - M[k]) / S[k], ctx);
+    for (int k = 0; k < C2; ++k) ctx = fmaf(g[k], expf(ldx<T>(p.in, px0 + px, C2, k) - M[k]) / S[k], ctx);
     msp[px] = 1.f / (1.f + expf(-ctx));
   }
   __syncthreads();
-  const T* x1 = reinterpret_cast<const T*>(p.res) + (size_t)n * HW * C;
-  T* o = reinterpret_cast<T*>(p.out) + (size_t)n * HW * C;
-  for (int i = t; i < HW * C; i += 256) o[i] = (T)(ldf(x1 + i) * msp[i / C]);
+  for (int i = t; i < HW * C; i += 256) stx<T>(p.out, px0 + i / C, C, i % C, ldx<T>(p.res, px0 + i / C, C, i % C) * msp[i / C]);
 }
 
 static int check_psa_c(int C) {
@@ -226,13 +247,14 @@ int describe_psa(const ConvParams& p, int dtype, int kind, Launch* out) {
   out->block = dim3(256);
   out->p = p;
   out->lds = 0;
-  if (dtype != UDP_F32 && dtype != UDP_BF16) return fail(UDP_ERR_UNSUPPORTED, "polarized self-attention ops: fp32 or bf16 storage only");
-  const bool f = dtype == UDP_F32;
+  if (dtype != UDP_F32 && dtype != UDP_BF16 && dtype != UDP_F16X2) return fail(UDP_ERR_ARG, "polarized self-attention ops: dtype %d", dtype);
+  auto pick = [&](const void* kf, const void* kb, const void* kh) { return dtype == UDP_F32 ? kf : dtype == UDP_BF16 ? kb : kh; };
   switch (kind) {
     case UDP_OP_PSA_POOL: {
       const int rc = check_psa_c(p.Cin);
       if (rc) return rc;
-      out->fn = f ? reinterpret_cast<const void*>(&psa_pool_kernel<float>) : reinterpret_cast<const void*>(&psa_pool_kernel<__bf16>);
+      out->fn = pick(reinterpret_cast<const void*>(&psa_pool_kernel<float>), reinterpret_cast<const void*>(&psa_pool_kernel<__bf16>),
+                     reinterpret_cast<const void*>(&psa_pool_kernel<H2>));
       out->grid = dim3(p.N);
       out->lds = (unsigned)((HW + 512) * sizeof(float));
       return UDP_OK;
@@ -245,7 +267,8 @@ int describe_psa(const ConvParams& p, int dtype, int kind, Launch* out) {
       return UDP_OK;
     }
     case UDP_OP_PSA_SCALE: {
-      out->fn = f ? reinterpret_cast<const void*>(&psa_scale_kernel<float>) : reinterpret_cast<const void*>(&psa_scale_kernel<__bf16>);
+      out->fn = pick(reinterpret_cast<const void*>(&psa_scale_kernel<float>), reinterpret_cast<const void*>(&psa_scale_kernel<__bf16>),
+                     reinterpret_cast<const void*>(&psa_scale_kernel<H2>));
       long blocks = ((long)p.N * HW * p.Cin + 255) / 256;
       out->grid = dim3((unsigned)(blocks > 8192 ? 8192 : blocks));
       return UDP_OK;
@@ -253,7 +276,8 @@ int describe_psa(const ConvParams& p, int dtype, int kind, Launch* out) {
     case UDP_OP_PSA_SP: {
       const int rc = check_psa_c(p.Cout);
       if (rc) return rc;
-      out->fn = f ? reinterpret_cast<const void*>(&psa_sp_kernel<float>) : reinterpret_cast<const void*>(&psa_sp_kernel<__bf16>);
+      out->fn = pick(reinterpret_cast<const void*>(&psa_sp_kernel<float>), reinterpret_cast<const void*>(&psa_sp_kernel<__bf16>),
+                     reinterpret_cast<const void*>(&psa_sp_kernel<H2>));
       out->grid = dim3(p.N);
       out->lds = (unsigned)((HW + 256 + 3 * p.Cin) * sizeof(float));
       return UDP_OK;

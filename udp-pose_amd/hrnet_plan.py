@@ -193,8 +193,6 @@ class HRNetProgram:
         if block.numel() != want:
             raise ValueError("%s: PSA parameter shapes do not match planes=%d" % (p, C))
         w_off = self._put(block.numpy().tobytes())
-        if self.dtype == "f16x2":
-            raise ValueError("pose_hrnet_psa: the attention kernels run on fp32 or bf16 storage only")
         f = 4 // storage_bytes(self.dtype)                               # fp32 side rows, counted in dtype elements
         base = dict(ks=1, stride=1, relu=0, cout_pad=_round_up(C, 32), hin=x.h, win=x.w, hout=x.h, wout=x.w,
                     res=None, ups=[], w_off=w_off, b_off=0)

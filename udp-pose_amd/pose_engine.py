@@ -99,7 +99,7 @@ class UdpPsaPoseHip:
 
     SKELETONS = SKELETONS
 
-    def __init__(self, model_path, config_path, device="cuda", dtype="f16x2", state_dict=None, config=None):
+    def __init__(self, model_path, config_path, device="cuda", dtype=None, state_dict=None, config=None):
         self.config = config if config is not None else load_config(config_path)
         self.input_shape = list(self.config.MODEL.IMAGE_SIZE)          # [w, h]
         ds = str(self.config.DATASET.DATASET).lower()
@@ -107,6 +107,8 @@ class UdpPsaPoseHip:
         self.flip_pairs = MPII_FLIP_PAIRS if ds == "mpii" else COCO_FLIP_PAIRS
         self.config.TEST.MODEL_FILE = model_path
         self._device = torch.device(device)
+        if dtype is None:
+            dtype = "f16x2"           # the parity-grade fast mode (fp32-level results on the fp16 matrix pipe)
         self.model = MODELS[self.config.MODEL.NAME](self.config, is_train=False, dtype=dtype)
         if state_dict is None:
             state_dict = torch.load(model_path, map_location="cpu", weights_only=True)
