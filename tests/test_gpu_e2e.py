@@ -338,13 +338,14 @@ def test_rsn18_matches_reference_heatmaps(golden_dir, och, tt):
     assert np.isfinite(rms) and rms < 0.8 * g["out"].std()
 
 
-def test_batches_past_the_launch_limit_are_split():
+@pytest.mark.parametrize("dtype", ["f32", "f16x2"])
+def test_batches_past_the_launch_limit_are_split(dtype):
     """A batch whose largest activation would exceed the 32-bit offsets of one launch is run in slices
     (here the limit is lowered to 2 images): same result, flip-test row order kept (all plain rows, then
     all mirrored rows)."""
     extra = synth.scaled_extra(32, modules=(1, 1, 1), blocks=1)
     sd = synth.synth_state_dict(extra, 17, "gaussian", seed=4)
-    net = MODELS["pose_hrnet"](_cfg(extra, 17, "gaussian"), is_train=False).load_state_dict(sd).to("cuda")
+    net = MODELS["pose_hrnet"](_cfg(extra, 17, "gaussian"), is_train=False, dtype=dtype).load_state_dict(sd).to("cuda")
     x = torch.from_numpy(synth.synth_crops(5, 64, 64, seed=8)).cuda()
     whole_flip = net.raw_forward(x, flip_test=True).clone()
     whole = net(x).clone()
