@@ -43,7 +43,7 @@ def main():
     op.kind, op.ks, op.stride, op.relu = _lib.UDP_OP_CONV, ks, st, 1
     op.cin, op.cout, op.cout_pad = cin, cout, (cout + 31) // 32 * 32
     op.hin, op.win, op.hout, op.wout = h, w, ho, wo
-    nslots = 65536 * 4 * 8
+    nslots = 65536 * 4 * 16
     stamps = torch.zeros(nslots, dtype=torch.int64, device="cuda")
 
     def run():
@@ -59,7 +59,7 @@ def main():
     run()
     e1.record()
     torch.cuda.synchronize()
-    s = stamps.cpu().numpy().reshape(-1, 8)
+    s = stamps.cpu().numpy().reshape(-1, 16)[:, :8]
     s = s[s[:, 0] != 0]
     print("%d waves, launch %.1f us (with stamps)" % (len(s), e0.elapsed_time(e1) * 1e3))
     names = ["prologue", "issue DMA c0", "wait DMA c0", "barrier", "MFMA loop (+later chunks)", "epilogue issue", "store drain"]

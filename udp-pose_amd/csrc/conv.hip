@@ -43,6 +43,9 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 // end; lo*lo ~ 2^-22 is dropped), i.e. fp32-grade results on the 2.5 PF fp16 matrix pipe instead of the
 // 157 TF fp32 one.  Memory layout: per pixel (or weight row) the C hi values, then the C lo values.
 struct H2 {};
+#ifndef UDP_WS_AD
+#define UDP_WS_AD 3     // A-fragment ring depth of the weight-stationary kernels (4 / 5: 245 / 256 registers, -0.6 / -1.5 %)
+#endif
 #ifndef UDP_WS_DBG
 #define UDP_WS_DBG 0   // ablation bits for diagnostic builds (tools/ablate_ws.sh): 1 no A prefetch, 2 no B reads, 4 no DMA after chunk 0
 #endif
@@ -81,12 +84,22 @@ __device__ __forceinline__ void stamp(int k) {
   unsigned long long t;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
   __builtin_amdgcn_sched_barrier(0);
-  if ((threadIdx.x & 63) == 0 && g_stamps)
-    g_stamps[((size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 4 + (threadIdx.x >> 6)) * 8 + k] = t;
+  if ((threadIdx.x & 63) == 0 && g_stamps) {
+    unsigned long long* q = g_stamps + ((size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 4 + (threadIdx.x >> 6)) * 16;
+    q[k] = t;
+    if (k == 0)   // where the wave runs: HW_REG_XCC_ID (20) in the high word, HW_REG_HW_ID (4: CU_ID[11:8], SE_ID[15:13]) in the low
+      q[8] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) | __builtin_amdgcn_s_getreg(4 | (31 << 11));
+  }
 }
 #define UDP_STAMP(k) stamp(k)
+#ifdef UDP_STAMPS_WS_ONLY          // tools/stamp_multi.py: only the weight-stationary kernels leave stamps
+#define UDP_STAMP_MFMA(k)
+#else
+#define UDP_STAMP_MFMA(k) stamp(k)
+#endif
 #else
 #define UDP_STAMP(k)
+#define UDP_STAMP_MFMA(k)
 #endif
 
 template <typename T>
@@ -387,7 +400,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int ti
   constexpr int WGROUPS = TAPS * BN / 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-  UDP_STAMP(0);
+  UDP_STAMP_MFMA(0);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -515,7 +528,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int ti
       for (int nb = 0; nb < NB; ++nb) acc[i][nb] = bias[nb];
   }
 
-  UDP_STAMP(1);
+  UDP_STAMP_MFMA(1);
   stage(0, smem);
   // The residual is added into the accumulators up front (acc = bias + res, then += conv): its loads fly
   // behind chunk 0's DMA and land under the same wait, instead of a second exposed round trip in the
@@ -527,7 +540,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int ti
         add_vec_buf<T, NB>(acc[i], r_res, opix[i] >= 0 ? (unsigned)opix[i] * respb + (p.res_coff + cbase) * ESZ : kOobOff, res_lo);
     }
   }
-  UDP_STAMP(2);
+  UDP_STAMP_MFMA(2);
   for (int c = 0; c < nchunks; ++c) {
     // chunk c has landed (explicit wait: the compiler is not obliged to track LDS-DMA) and every
     // wave is done with chunk c-1
@@ -536,9 +549,9 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int ti
       stage(c, smem);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (c == 0) UDP_STAMP(3);
+    if (c == 0) UDP_STAMP_MFMA(3);
     __syncthreads();
-    if (c == 0) UDP_STAMP(4);
+    if (c == 0) UDP_STAMP_MFMA(4);
     if (!p.sbuf && c + 1 < nchunks) stage(c + 1, smem + ((c + 1) & 1) * stage_bytes);
     const unsigned char* sb = p.sbuf ? smem : smem + (c & 1) * stage_bytes;
     if constexpr (PL == 2)
@@ -553,7 +566,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int ti
       for (int nb = 0; nb < NB; ++nb) acc[i][nb] += accx[i][nb] * kLoInv;
   }
 
-  UDP_STAMP(5);
+  UDP_STAMP_MFMA(5);
   // BatchNorm statistics of the output (training, p.bn_ws): per-lane sums of x and x*x over its pixels, of the
   // values AS STORED (rounded to T) -- what the normalisation pass will read
   // (fp64 like the separate statistics pass: var = E[x^2] - mean^2 cancels for channels with |mean| >> std)
@@ -654,10 +667,10 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int ti
       }
     }
   }
-  UDP_STAMP(6);
+  UDP_STAMP_MFMA(6);
 #ifdef UDP_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  UDP_STAMP(7);
+  UDP_STAMP_MFMA(7);
 #endif
 }
 
@@ -792,7 +805,8 @@ __device__ __forceinline__ void conv_ws_body(const ConvParams& p, const int tile
   const unsigned wpair = (unsigned)(cby * CP + cp) * 4096u;
   // A fragments of one tap (2 blocks x hi/lo = 16 registers) in a ring of three: the fragments of step s + 2
   // stream in from L2 while step s feeds the MFMAs (step = one tap of one K chunk)
-  f16x8 ah[3][NB], al[3][NB];
+  constexpr int AD = UDP_WS_AD;          // depth of the A ring (fragments of step s + AD - 1 are in flight)
+  f16x8 ah[AD][NB], al[AD][NB];
   const int nsteps = nchunks * TAPS;
   auto load_a = [&](int s, f16x8 (&h)[NB], f16x8 (&l)[NB]) __attribute__((always_inline)) {
     const int c = s / TAPS, tap = s - c * TAPS;
@@ -818,8 +832,8 @@ __device__ __forceinline__ void conv_ws_body(const ConvParams& p, const int tile
       }
   }
 
-  load_a(0, ah[0], al[0]);
-  load_a(nsteps > 1 ? 1 : 0, ah[1], al[1]);
+#pragma unroll
+  for (int k = 0; k < AD - 1; ++k) load_a(k < nsteps ? k : nsteps - 1, ah[k], al[k]);
   if constexpr (!NCHW) {
     if (p.res) {
 #pragma unroll
@@ -838,12 +852,12 @@ __device__ __forceinline__ void conv_ws_body(const ConvParams& p, const int tile
     // (issued unconditionally -- past the end the last step's fragments are fetched again: a prefetch under a
     // branch makes hipcc assume nothing newer is in flight and wait with vmcnt(0) at every use)
 #if !(UDP_WS_DBG & 1)
-    load_a(s + 2 < nsteps ? s + 2 : nsteps - 1, ah[(BUF + 2) % 3], al[(BUF + 2) % 3]);
+    load_a(s + AD - 1 < nsteps ? s + AD - 1 : nsteps - 1, ah[(BUF + AD - 1) % AD], al[(BUF + AD - 1) % AD]);
 #endif
     if (tap == 0) {
       // chunk c's DMA has landed (vector-memory operations complete in issue order: all but the 2*NB A loads
-      // just issued, which may stay in flight)
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      // just issued, which may stay in flight; letting the previous step's stay in flight too changes nothing)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB) : "memory");
       if (s == 0) UDP_STAMP(3);
       __syncthreads();                                    // ... for every wave; nobody reads the other stage any more
       if (s == 0) UDP_STAMP(4);
@@ -882,10 +896,13 @@ __device__ __forceinline__ void conv_ws_body(const ConvParams& p, const int tile
       ++c;
     }
   };
-  for (int s = 0; s < nsteps; s += 3) {
+  for (int s = 0; s < nsteps; s += AD) {
     step(std::integral_constant<int, 0>{}, s);
     if (s + 1 < nsteps) step(std::integral_constant<int, 1>{}, s + 1);
     if (s + 2 < nsteps) step(std::integral_constant<int, 2>{}, s + 2);
+    if constexpr (AD > 3) if (s + 3 < nsteps) step(std::integral_constant<int, 3>{}, s + 3);
+    if constexpr (AD > 4) if (s + 4 < nsteps) step(std::integral_constant<int, 4>{}, s + 4);
+    if constexpr (AD > 5) if (s + 5 < nsteps) step(std::integral_constant<int, 5>{}, s + 5);
   }
   UDP_STAMP(5);
 #pragma unroll
@@ -955,9 +972,14 @@ __global__ __launch_bounds__(256, 2) void conv_ws_h2_kernel(const ConvParams p) 
 template <int KS>
 __global__ __launch_bounds__(256, 2) void conv_ws_multi(const ConvMulti m) {
   const unsigned b = blockIdx.x;
-  const int j = (b >= m.start[1]) + (b >= m.start[2]) + (b >= m.start[3]);
-  const unsigned r = b - m.start[j];
-  const unsigned cby = r / m.tiles[j];
+  int sg = 0;
+#pragma unroll
+  for (int k = 1; k < kMultiSegs; ++k) sg += b >= m.seg_start[k];
+  // (readfirstlane: the dynamically indexed kernel-argument reads are uniform, the compiler does not see it and
+  // would wrap every weight load of the body in a waterfall loop)
+  const int j = __builtin_amdgcn_readfirstlane(m.seg_mem[sg]);
+  const unsigned r = __builtin_amdgcn_readfirstlane(b - m.seg_start[sg] + m.seg_first[sg]);
+  const unsigned cby = __builtin_amdgcn_readfirstlane(r / m.tiles[j]);
   const int tile = (int)(r - cby * m.tiles[j]);
   switch (m.code[j]) {
     case 1: conv_ws_body<KS, 1, 6, 1, false>(m.p[j], tile, (int)cby); break;
@@ -2224,6 +2246,69 @@ int describe_conv_grouped(ConvParams p, int dtype, int ks, int stride, Launch* o
   return UDP_OK;
 }
 
+// Dispatch order of a merged weight-stationary launch.  Members arrive deepest-K first: long, matrix-bound
+// workgroups (a 256-channel workgroup lives ~65 us, 72 K steps) down to the short HBM-bound 32-channel ones
+// (~15 us).  Workgroups are dispatched in flat-index order, breadth first over the CUs.  Member after member
+// (longest first) leaves the second half of the launch to the shallow member alone -- HBM-bound at ~4.9 TB/s while
+// the matrix pipe idles, after a first half in which HBM idles (in-kernel timeline, tools/stamp_multi.py).  So the
+// grid alternates chunks of the deep members (list A, longest first) with chunks of the shallowest member (list
+// B), in the proportion that exhausts both lists together: every CU holds both kinds for the whole launch, the
+// deepest workgroups still all start in the first round, and the last workgroups to start are short ones.
+// Chunks are multiples of 8 workgroups (one per XCD -- workgroup i runs on XCD i % 8, an uneven pattern would
+// leave some XCDs with all the long workgroups).  UDP_POSE_WS_ORDER=lpt keeps the plain member-after-member order.
+static void ws_order(ConvMulti* m, int n) {
+  unsigned lo[4], hi[4];
+  unsigned total = 0;
+  for (int j = 0; j < n; ++j) {
+    lo[j] = 0;
+    hi[j] = (j + 1 < n ? m->start[j + 1] : m->start[4]) - m->start[j];
+    total += hi[j];
+  }
+  int ns = 0;
+  unsigned at = 0;
+  auto take = [&](int j, unsigned cnt) {
+    if (cnt > hi[j] - lo[j]) cnt = hi[j] - lo[j];
+    if (!cnt) return;
+    if (!(ns && m->seg_mem[ns - 1] == j && m->seg_first[ns - 1] + (at - m->seg_start[ns - 1]) == lo[j])) {
+      m->seg_start[ns] = at;
+      m->seg_first[ns] = lo[j];
+      m->seg_mem[ns] = j;
+      ++ns;
+    }
+    lo[j] += cnt;
+    at += cnt;
+  };
+  const char* mode = getenv("UDP_POSE_WS_ORDER");
+  if (!(mode && strcmp(mode, "lpt") == 0)) {
+    // chunk size: 32 workgroups, more when the table would not hold the launch (two entries stay free per member)
+    unsigned g = 32;
+    while ((total + g - 1) / g > (unsigned)(kMultiSegs - 2 * n)) g += 8;
+    const unsigned nb = hi[n - 1];
+    const unsigned na = total - nb;
+    unsigned ta = 0, tb = 0;                 // taken from A / B so far
+    while (ta < na && tb < nb && ns < kMultiSegs - n) {
+      // the list that is behind its share goes next (ties: A, so that the deepest workgroups lead the grid)
+      if ((unsigned long long)ta * nb <= (unsigned long long)tb * na) {
+        int j = 0;
+        while (lo[j] == hi[j]) ++j;
+        const unsigned c = hi[j] - lo[j] < g ? hi[j] - lo[j] : g;
+        take(j, c);
+        ta += c;
+      } else {
+        const unsigned c = nb - tb < g ? nb - tb : g;
+        take(n - 1, c);
+        tb += c;
+      }
+    }
+  }
+  for (int j = 0; j < n; ++j) take(j, hi[j] - lo[j]);
+  for (int s = ns; s < kMultiSegs; ++s) {
+    m->seg_start[s] = 0xFFFFFFFFu;
+    m->seg_first[s] = 0;
+    m->seg_mem[s] = 0;
+  }
+}
+
 // Kernel + attribute for a merged launch of `n` groupable convs; fills the kernel argument.
 int describe_multi(const Launch* members, int n, ConvMulti* m, Launch* out) {
   static bool attr_set = false;
@@ -2260,6 +2345,7 @@ int describe_multi(const Launch* members, int n, ConvMulti* m, Launch* out) {
     }
     for (int j = n; j < 5; ++j) m->start[j] = j < 4 ? 0xFFFFFFFFu : total;
     for (int j = n; j < 4; ++j) m->tiles[j] = 1;
+    ws_order(m, n);
     out->fn = wk[members[0].groupable / 10 % 10 == 3 ? 0 : 1];
     out->grid = dim3(total);
     out->block = dim3(256);
