@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UDP_POSE_ABI_VERSION 14
+#define UDP_POSE_ABI_VERSION 15
 
 enum udp_status {
   UDP_OK = 0,
@@ -317,6 +317,35 @@ int udp_bn_train_fwd_from_sums(const void* x, int64_t m, int c, const float* gam
 int udp_bn_train_bwd(const void* x, const void* dy, const void* y_relu, int64_t m, int c,
                      const float* gamma, const float* save_mean, const float* save_invstd, float* dgamma,
                      float* dbeta, void* dx, void* g_out, int dtype, double* ws, void* stream);
+/* Up to 4 BatchNorms per call (the bn1 / bn2 of one block depth of every HRNet branch are independent,
+ * pose_hrnet.py:253-256: train.py runs the branches in lock step): each pass is ONE launch over all tensors,
+ * per-tensor arithmetic and results are those of the single-tensor entry points above, bit for bit.
+ * Forward reads x, gamma, beta, running_*, res, relu, rows (> 0: `ws` already holds that many partial rows from
+ * udp_conv2d_fused_bn; 0: the partial sums are computed here) and writes save_*, y.  Backward reads x, dy, y_relu,
+ * gamma, save_* and writes dgamma, dbeta, dx, g_out (optional).  Every tensor needs its own `ws`
+ * (udp_bn_workspace_doubles(c) doubles). */
+typedef struct udp_bn_item {
+  const void* x;
+  const void* dy;
+  const void* y_relu;
+  const void* res;
+  void* y;
+  void* dx;
+  void* g_out;
+  const float* gamma;
+  const float* beta;
+  float* running_mean;
+  float* running_var;
+  float* save_mean;
+  float* save_invstd;
+  float* dgamma;
+  float* dbeta;
+  double* ws;
+  int64_t m;
+  int32_t c, rows, relu, reserved;
+} udp_bn_item;
+int udp_bn_train_fwd_multi(const udp_bn_item* items, int n, float eps, float momentum, int dtype, void* stream);
+int udp_bn_train_bwd_multi(const udp_bn_item* items, int n, int dtype, void* stream);
 /* acc[n,y,x,c] (init ? = : +=) src[n, y>>shift, x>>shift, c], optional ReLU: the sum nodes of
  * HighResolutionModule.forward (pose_hrnet.py:266-272) with nn.Upsample(mode='nearest'). */
 int udp_ew_accumulate(void* acc, const void* src, int n, int h, int w, int c, int shift, int init,

@@ -16,8 +16,15 @@ DTYPES = {"f32": UDP_F32, "bf16": UDP_BF16, "f16x2": UDP_F16X2}
 UDP_OP_STEM, UDP_OP_CONV, UDP_OP_FUSE, UDP_OP_STEM7, UDP_OP_MAXPOOL, UDP_OP_BILINEAR = 0, 1, 2, 3, 4, 5
 UDP_OP_PSA_POOL, UDP_OP_PSA_MLP, UDP_OP_PSA_SCALE, UDP_OP_PSA_SP, UDP_OP_BLOCK = 6, 7, 8, 9, 10
 UDP_BUF_NONE, UDP_BUF_OUTPUT = -1, -2
-ABI_VERSION = 14
+ABI_VERSION = 15
 MAX_LANES, MAX_WAIT = 4, 8
+
+
+class BnItem(C.Structure):
+    """struct udp_bn_item (include/udp_pose_hip.h): one tensor of a multi-tensor BatchNorm call."""
+    _fields_ = [(k, C.c_void_p) for k in ("x", "dy", "y_relu", "res", "y", "dx", "g_out", "gamma", "beta", "running_mean",
+                                          "running_var", "save_mean", "save_invstd", "dgamma", "dbeta", "ws")] + [
+        ("m", C.c_int64), ("c", C.c_int32), ("rows", C.c_int32), ("relu", C.c_int32), ("reserved", C.c_int32)]
 
 
 class ConvOp(C.Structure):
@@ -97,6 +104,8 @@ _SIGS = {
     "udp_bn_train_fwd_from_sums": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P, _P,
                                              C.c_int, _P, C.c_int, _P, C.c_int, _P]),
     "udp_bn_train_bwd": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
+    "udp_bn_train_fwd_multi": (C.c_int, [_P, C.c_int, C.c_float, C.c_float, C.c_int, _P]),
+    "udp_bn_train_bwd_multi": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "udp_ew_accumulate": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_int, _P]),
     "udp_relu_bwd": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, _P]),

@@ -383,18 +383,20 @@ __device__ __forceinline__ void st4(T* p, f32x4 v) {
   }
 }
 
+// (bx, nbx) = the workgroup's index / the number of workgroups working on THIS tensor: the single-tensor kernels
+// pass blockIdx.x / gridDim.x, the multi-tensor kernels (bn_multi_*) the position inside the tensor's block range
 template <typename T, int MODE>
-__global__ __launch_bounds__(256) void bn_sums_kernel(const T* __restrict__ x, const T* __restrict__ dy,
-                                                      const T* __restrict__ y, const float* __restrict__ mean,
-                                                      const float* __restrict__ invstd, long m, int C,
-                                                      double* __restrict__ ws) {
+__device__ __forceinline__ void bn_sums_body(const T* __restrict__ x, const T* __restrict__ dy,
+                                             const T* __restrict__ y, const float* __restrict__ mean,
+                                             const float* __restrict__ invstd, long m, int C,
+                                             double* __restrict__ ws, unsigned bx, unsigned nbx) {
   __shared__ double red[256][8];
   const int t = threadIdx.x;
   const int CG = C >> 2;                       // channel quads
   const int CT = CG < 256 ? CG : 256, RG = 256 / CT;
-  const long rows_per_block = (m + gridDim.x - 1) / gridDim.x;
-  const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, m);
-  double* out = ws + (long)blockIdx.x * 2 * C;
+  const long rows_per_block = (m + nbx - 1) / nbx;
+  const long r0 = (long)bx * rows_per_block, r1 = min(r0 + rows_per_block, m);
+  double* out = ws + (long)bx * 2 * C;
   for (int cb = 0; cb < CG; cb += CT) {
     const int cg = cb + t % CT;
     double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
@@ -449,6 +451,13 @@ __global__ __launch_bounds__(256) void bn_sums_kernel(const T* __restrict__ x, c
     __syncthreads();
   }
 }
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void bn_sums_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                      const T* __restrict__ y, const float* __restrict__ mean,
+                                                      const float* __restrict__ invstd, long m, int C,
+                                                      double* __restrict__ ws) {
+  bn_sums_body<T, MODE>(x, dy, y, mean, invstd, m, C, ws, blockIdx.x, gridDim.x);
+}
 
 // Sum of the per-block partial rows for 4 channels per workgroup: 64 row lanes per channel, then a
 // fixed-order LDS reduction (deterministic).  Valid in threads with kl == 0.
@@ -473,10 +482,10 @@ __device__ __forceinline__ void bn_collect(const double* ws, int nblocks, int C,
   }
 }
 
-__global__ void bn_fwd_finalize_kernel(double* __restrict__ ws, int nblocks, long m, int C, float eps, float momentum,
-                                       float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ smean,
-                                       float* __restrict__ sinvstd) {
-  const int c = blockIdx.x * 4 + (threadIdx.x & 3);
+__device__ __forceinline__ void bn_fwd_finalize_body(double* __restrict__ ws, int nblocks, long m, int C, float eps, float momentum,
+                                                     float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ smean,
+                                                     float* __restrict__ sinvstd, unsigned bx) {
+  const int c = bx * 4 + (threadIdx.x & 3);
   double s0, s1;
   bn_collect(ws, nblocks, C, c, s0, s1);
   if (c >= C || (threadIdx.x >> 2)) return;
@@ -488,14 +497,19 @@ __global__ void bn_fwd_finalize_kernel(double* __restrict__ ws, int nblocks, lon
   if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mu;
   if (rvar) rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)(m > 1 ? var * (double)m / (double)(m - 1) : var);
 }
+__global__ void bn_fwd_finalize_kernel(double* __restrict__ ws, int nblocks, long m, int C, float eps, float momentum,
+                                       float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ smean,
+                                       float* __restrict__ sinvstd) {
+  bn_fwd_finalize_body(ws, nblocks, m, C, eps, momentum, rmean, rvar, smean, sinvstd, blockIdx.x);
+}
 
 // y = [relu]((x - mean) * invstd * gamma + beta [+ res]); 4 channels per thread
 template <typename T>
-__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res,
-                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       long total4, int C, int relu, T* __restrict__ y) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+__device__ __forceinline__ void bn_apply_body(const T* __restrict__ x, const T* __restrict__ res,
+                                              const float* __restrict__ mean, const float* __restrict__ invstd,
+                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                              long total4, int C, int relu, T* __restrict__ y, unsigned bx, unsigned nbx) {
+  for (long i = (long)bx * 256 + threadIdx.x; i < total4; i += (long)nbx * 256) {
     const int c = (int)((i * 4) % C);
     const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
     const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
@@ -508,10 +522,17 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     st4(y + i * 4, v);
   }
 }
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       long total4, int C, int relu, T* __restrict__ y) {
+  bn_apply_body<T>(x, res, mean, invstd, gamma, beta, total4, C, relu, y, blockIdx.x, gridDim.x);
+}
 
-__global__ void bn_bwd_finalize_kernel(double* __restrict__ ws, int nblocks, int C, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, float* __restrict__ sums) {
-  const int c = blockIdx.x * 4 + (threadIdx.x & 3);
+__device__ __forceinline__ void bn_bwd_finalize_body(double* __restrict__ ws, int nblocks, int C, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, float* __restrict__ sums, unsigned bx) {
+  const int c = bx * 4 + (threadIdx.x & 3);
   double s0, s1;
   bn_collect(ws, nblocks, C, c, s0, s1);
   if (c >= C || (threadIdx.x >> 2)) return;
@@ -520,15 +541,19 @@ __global__ void bn_bwd_finalize_kernel(double* __restrict__ ws, int nblocks, int
   sums[c] = (float)s0;
   sums[C + c] = (float)s1;
 }
+__global__ void bn_bwd_finalize_kernel(double* __restrict__ ws, int nblocks, int C, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, float* __restrict__ sums) {
+  bn_bwd_finalize_body(ws, nblocks, C, dgamma, dbeta, sums, blockIdx.x);
+}
 
 // g = dy*(y>0);  dx = gamma*invstd*(g - dbeta/m - xhat*dgamma/m);  optional g_out = g
 template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
-                                                           const T* __restrict__ y, const float* __restrict__ mean,
-                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                           const float* __restrict__ sums, long total4, int C, float inv_m,
-                                                           T* __restrict__ dx, T* __restrict__ g_out) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+__device__ __forceinline__ void bn_bwd_apply_body(const T* __restrict__ x, const T* __restrict__ dy,
+                                                  const T* __restrict__ y, const float* __restrict__ mean,
+                                                  const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                  const float* __restrict__ sums, long total4, int C, float inv_m,
+                                                  T* __restrict__ dx, T* __restrict__ g_out, unsigned bx, unsigned nbx) {
+  for (long i = (long)bx * 256 + threadIdx.x; i < total4; i += (long)nbx * 256) {
     const int c = (int)((i * 4) % C);
     const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
     const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
@@ -545,6 +570,56 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     if (g_out) st4(g_out + i * 4, g);
   }
 }
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                           const T* __restrict__ y, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const float* __restrict__ sums, long total4, int C, float inv_m,
+                                                           T* __restrict__ dx, T* __restrict__ g_out) {
+  bn_bwd_apply_body<T>(x, dy, y, mean, invstd, gamma, sums, total4, C, inv_m, dx, g_out, blockIdx.x, gridDim.x);
+}
+
+// ---- the same five passes over up to 4 tensors per launch (the BatchNorms of one block depth of all HRNet
+// branches are independent: train.py runs the branches in lock step).  A workgroup finds its tensor from the
+// block-range table; per-tensor arithmetic and block partition are those of the single-tensor kernels, so the
+// results are bit-identical.
+struct BnMulti {
+  udp_bn_item it[4];
+  unsigned start[5];       // first block of tensor j in this launch; start[n..4] = total
+  float eps, momentum;
+};
+#define UDP_BN_PICK                                                                              \
+  const unsigned b = blockIdx.x;                                                                   \
+  const int j = __builtin_amdgcn_readfirstlane((b >= a.start[1]) + (b >= a.start[2]) + (b >= a.start[3])); \
+  const udp_bn_item& q = a.it[j];                                                                  \
+  const unsigned bx = b - a.start[j], nbx = a.start[j + 1] - a.start[j];                           \
+  (void)nbx;
+template <typename T>
+__global__ __launch_bounds__(256) void bn_multi_sums_bwd(const BnMulti a) {
+  UDP_BN_PICK
+  bn_sums_body<T, 1>((const T*)q.x, (const T*)q.dy, (const T*)q.y_relu, q.save_mean, q.save_invstd, q.m, q.c, q.ws, bx, nbx);
+}
+__global__ void bn_multi_fin_fwd(const BnMulti a) {
+  UDP_BN_PICK
+  bn_fwd_finalize_body(q.ws, q.rows, q.m, q.c, a.eps, a.momentum, q.running_mean, q.running_var, q.save_mean, q.save_invstd, bx);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void bn_multi_apply_fwd(const BnMulti a) {
+  UDP_BN_PICK
+  bn_apply_body<T>((const T*)q.x, (const T*)q.res, q.save_mean, q.save_invstd, q.gamma, q.beta, q.m * q.c / 4, q.c, q.relu, (T*)q.y, bx, nbx);
+}
+__global__ void bn_multi_fin_bwd(const BnMulti a) {
+  UDP_BN_PICK
+  bn_bwd_finalize_body(q.ws, q.rows, q.c, q.dgamma, q.dbeta, reinterpret_cast<float*>(q.ws + (size_t)kBnMaxBlocks * 2 * q.c), bx);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void bn_multi_apply_bwd(const BnMulti a) {
+  UDP_BN_PICK
+  bn_bwd_apply_body<T>((const T*)q.x, (const T*)q.dy, (const T*)q.y_relu, q.save_mean, q.save_invstd, q.gamma,
+                       reinterpret_cast<const float*>(q.ws + (size_t)kBnMaxBlocks * 2 * q.c), q.m * q.c / 4, q.c, 1.f / (float)q.m,
+                       (T*)q.dx, (T*)q.g_out, bx, nbx);
+}
+#undef UDP_BN_PICK
 
 // ---------------------------------------------------------------------------------------------
 // element-wise nodes
@@ -854,6 +929,80 @@ extern "C" int udp_bn_train_bwd(const void* x, const void* dy, const void* y_rel
                  (bn_bwd_apply_kernel<float><<<nblocks(total4, 256 * 2), 256, 0, s>>>((const float*)x, (const float*)dy, (const float*)y_relu, save_mean, save_invstd, gamma, sums, total4, c, inv_m, (float*)dx, (float*)g_out)),
                  (bn_bwd_apply_kernel<__bf16><<<nblocks(total4, 256 * 2), 256, 0, s>>>((const __bf16*)x, (const __bf16*)dy, (const __bf16*)y_relu, save_mean, save_invstd, gamma, sums, total4, c, inv_m, (__bf16*)dx, (__bf16*)g_out)));
   return launched("udp_bn_train_bwd");
+}
+
+static int bn_multi_check(const udp_bn_item* items, int n, int dtype, const char* who) {
+  if (!items || n < 1 || n > 4) return fail(UDP_ERR_ARG, "%s: %d tensors (1..4)", who, n);
+  if (check_dtype(dtype, who)) return UDP_ERR_ARG;
+  for (int j = 0; j < n; ++j) {
+    const udp_bn_item& q = items[j];
+    if (!q.x || !q.gamma || !q.save_mean || !q.save_invstd || !q.ws) return fail(UDP_ERR_ARG, "%s: tensor %d: null pointer", who, j);
+    if (q.m <= 0 || q.c <= 0 || (q.c & 3)) return fail(UDP_ERR_ARG, "%s: tensor %d: m=%lld c=%d (c must be a multiple of 4)", who, j, (long long)q.m, q.c);
+    if (q.rows < 0 || q.rows > kBnMaxBlocks) return fail(UDP_ERR_ARG, "%s: tensor %d: %d partial rows (0..%d)", who, j, q.rows, kBnMaxBlocks);
+  }
+  return UDP_OK;
+}
+
+extern "C" int udp_bn_train_fwd_multi(const udp_bn_item* items, int n, float eps, float momentum, int dtype, void* stream) {
+  if (bn_multi_check(items, n, dtype, "udp_bn_train_fwd_multi")) return UDP_ERR_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  BnMulti a{};
+  a.eps = eps;
+  a.momentum = momentum;
+  for (int j = 0; j < n; ++j) {
+    a.it[j] = items[j];
+    if (!a.it[j].beta || !a.it[j].y) return fail(UDP_ERR_ARG, "udp_bn_train_fwd_multi: tensor %d: null pointer", j);
+    if (a.it[j].rows == 0) {       // no conv-epilogue statistics for this one: its own partial-sum pass
+      const unsigned nb = bn_blocks(a.it[j].m, a.it[j].c);
+      UDP_DISPATCH_T(dtype,
+                     (bn_sums_kernel<float, 0><<<nb, 256, 0, s>>>((const float*)a.it[j].x, nullptr, nullptr, nullptr, nullptr, a.it[j].m, a.it[j].c, a.it[j].ws)),
+                     (bn_sums_kernel<__bf16, 0><<<nb, 256, 0, s>>>((const __bf16*)a.it[j].x, nullptr, nullptr, nullptr, nullptr, a.it[j].m, a.it[j].c, a.it[j].ws)));
+      a.it[j].rows = (int)nb;
+    }
+  }
+  unsigned tot = 0;
+  for (int j = 0; j < 5; ++j) {
+    a.start[j] = tot;
+    if (j < n) tot += (unsigned)(a.it[j].c + 3) / 4;
+  }
+  bn_multi_fin_fwd<<<tot, 256, 0, s>>>(a);
+  tot = 0;
+  for (int j = 0; j < 5; ++j) {
+    a.start[j] = tot;
+    if (j < n) tot += nblocks(a.it[j].m * a.it[j].c / 4, 256 * 2);
+  }
+  UDP_DISPATCH_T(dtype, (bn_multi_apply_fwd<float><<<tot, 256, 0, s>>>(a)), (bn_multi_apply_fwd<__bf16><<<tot, 256, 0, s>>>(a)));
+  return launched("udp_bn_train_fwd_multi");
+}
+
+extern "C" int udp_bn_train_bwd_multi(const udp_bn_item* items, int n, int dtype, void* stream) {
+  if (bn_multi_check(items, n, dtype, "udp_bn_train_bwd_multi")) return UDP_ERR_ARG;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  BnMulti a{};
+  unsigned tot = 0;
+  for (int j = 0; j < n; ++j) {
+    a.it[j] = items[j];
+    if (!a.it[j].dy || !a.it[j].dgamma || !a.it[j].dbeta || !a.it[j].dx) return fail(UDP_ERR_ARG, "udp_bn_train_bwd_multi: tensor %d: null pointer", j);
+    a.it[j].rows = (int)bn_blocks(a.it[j].m, a.it[j].c);
+  }
+  for (int j = 0; j < 5; ++j) {
+    a.start[j] = tot;
+    if (j < n) tot += (unsigned)a.it[j].rows;
+  }
+  UDP_DISPATCH_T(dtype, (bn_multi_sums_bwd<float><<<tot, 256, 0, s>>>(a)), (bn_multi_sums_bwd<__bf16><<<tot, 256, 0, s>>>(a)));
+  tot = 0;
+  for (int j = 0; j < 5; ++j) {
+    a.start[j] = tot;
+    if (j < n) tot += (unsigned)(a.it[j].c + 3) / 4;
+  }
+  bn_multi_fin_bwd<<<tot, 256, 0, s>>>(a);
+  tot = 0;
+  for (int j = 0; j < 5; ++j) {
+    a.start[j] = tot;
+    if (j < n) tot += nblocks(a.it[j].m * a.it[j].c / 4, 256 * 2);
+  }
+  UDP_DISPATCH_T(dtype, (bn_multi_apply_bwd<float><<<tot, 256, 0, s>>>(a)), (bn_multi_apply_bwd<__bf16><<<tot, 256, 0, s>>>(a)));
+  return launched("udp_bn_train_bwd_multi");
 }
 
 extern "C" int udp_ew_accumulate(void* acc, const void* src, int n, int h, int w, int c, int shift, int init, int relu,

@@ -12,6 +12,7 @@ Reference contract mirrored: ``JointsMSELoss`` / ``JointsMSELoss_offset`` (lib/c
 mean all-reduce of the flat gradient (dist.allreduce_mean_).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -32,13 +33,32 @@ def _is_param(k):
 
 class _Act:
     """An NHWC activation [n,h,w,ck] (ck = channels rounded up to 16) and its gradient."""
-    __slots__ = ("buf", "n", "h", "w", "c", "ck", "grad", "needs_grad", "bn_rows")
+    __slots__ = ("buf", "n", "h", "w", "c", "ck", "grad", "needs_grad", "bn_rows", "bn_ws")
 
     def __init__(self, buf, n, h, w, c, ck, needs_grad=True):
         self.buf, self.n, self.h, self.w, self.c, self.ck = buf, n, h, w, c, ck
         self.grad = None
         self.needs_grad = needs_grad
-        self.bn_rows = 0            # > 0: the conv that produced it left that many BatchNorm partial rows in _bn_ws
+        self.bn_rows = 0            # > 0: the conv that produced it left that many BatchNorm partial rows in bn_ws
+        self.bn_ws = None           # the BatchNorm workspace those rows are in
+
+
+class _Group:
+    """Tape entry of a multi-tensor op: its backward runs once every member's gradient is there (the members are
+    outputs of independent branches; in reverse tape order all their consumers precede the op)."""
+    __slots__ = ("ys",)
+
+    def __init__(self, ys):
+        self.ys = ys
+
+    @property
+    def grad(self):
+        return None if all(y.grad is None for y in self.ys) else True
+
+    @grad.setter
+    def grad(self, v):
+        for y in self.ys:
+            y.grad = v
 
 
 class HRNetTrainer:
@@ -97,10 +117,14 @@ class HRNetTrainer:
             descs[i].cout, descs[i].cin, descs[i].ks = cout, cin, ks
         self._pack_table = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(self.device)
         self._zeros = torch.zeros(1024, dtype=torch.float32, device=self.device)      # zero bias rows
-        self._bn_ws = torch.zeros(_lib.lib().udp_bn_workspace_doubles(1024), dtype=torch.float64, device=self.device)
+        # one BatchNorm workspace per branch slot: the branches of a module run in lock step (_blocks_lockstep), a
+        # conv's epilogue leaves its partial rows in its slot until the multi-tensor BatchNorm call has read them
+        self._bn_wss = [torch.zeros(_lib.lib().udp_bn_workspace_doubles(1024), dtype=torch.float64, device=self.device)
+                        for _ in range(4)]
+        self._bn_ws = self._bn_wss[0]
+        self.bn_multi = os.environ.get("UDP_POSE_NO_BN_MULTI") is None           # A/B knob
         self._loss = torch.zeros(2, dtype=torch.float64, device=self.device)
         self._tape = []
-        import os
         self.fuse_bn_stats = os.environ.get("UDP_POSE_NO_BN_FUSION") is None     # A/B knob
         # gradient buckets for the all-reduce (~25 MB each): consecutive parameters of the flat
         # gradient; a bucket is reduced as soon as the backward has written its last gradient, so the exchange
@@ -164,8 +188,9 @@ class HRNetTrainer:
         op.out_buf = _lib.UDP_BUF_OUTPUT if nchw else 0
         return op
 
-    def _conv(self, x, name, stride=1, bias_key=None, nchw_out=False, bn_stats=False):
+    def _conv(self, x, name, stride=1, bias_key=None, nchw_out=False, bn_stats=False, slot=0):
         L = _lib.lib()
+        bn_ws = self._bn_wss[slot]
         cout, cin, ks, wf, wd = self._convs[name]
         if x.c != cin:
             raise ValueError("%s: expects %d input channels, got %d" % (name, cin, x.c))
@@ -190,7 +215,7 @@ class HRNetTrainer:
             # the BatchNorm that follows reads its statistics from the conv epilogue's partial sums
             rows = C.c_int(0)
             rc = L.udp_conv2d_fused_bn(C.byref(op), self._dt, x.n, x.buf.data_ptr(), wf.data_ptr(), bias,
-                                       y.buf.data_ptr(), self._bn_ws.data_ptr(), self._bn_ws.numel(), C.byref(rows),
+                                       y.buf.data_ptr(), bn_ws.data_ptr(), bn_ws.numel(), C.byref(rows),
                                        self._stream())
             if rc == -4:       # UDP_ERR_WORKSPACE: more tiles than partial rows fit -> separate statistics pass
                 _lib.check(L.udp_conv2d_fused(C.byref(op), self._dt, x.n, x.buf.data_ptr(), wf.data_ptr(), bias, None,
@@ -198,6 +223,7 @@ class HRNetTrainer:
             else:
                 _lib.check(rc)
                 y.bn_rows = rows.value
+                y.bn_ws = bn_ws
         else:
             _lib.check(L.udp_conv2d_fused(C.byref(op), self._dt, x.n, x.buf.data_ptr(), wf.data_ptr(), bias, None, None,
                                           None, None, y.buf.data_ptr(), self._stream()))
@@ -236,7 +262,8 @@ class HRNetTrainer:
         save = torch.empty(2 * c, dtype=torch.float32, device=self.device)
         args = (x.buf.data_ptr(), m, c, self._p(name + ".weight"), self._p(name + ".bias"), BN_EPS, BN_MOMENTUM,
                 self._p(name + ".running_mean"), self._p(name + ".running_var"), save.data_ptr(), save.data_ptr() + 4 * c,
-                None if res is None else res.buf.data_ptr(), int(relu), y.buf.data_ptr(), self._dt, self._bn_ws.data_ptr())
+                None if res is None else res.buf.data_ptr(), int(relu), y.buf.data_ptr(), self._dt,
+                (x.bn_ws if x.bn_rows else self._bn_ws).data_ptr())
         if x.bn_rows:
             _lib.check(L.udp_bn_train_fwd_from_sums(*args, x.bn_rows, self._stream()))
         else:
@@ -260,6 +287,121 @@ class HRNetTrainer:
                                                    0, 0, 0, self._dt, self._stream()))
         self._tape.append((y, backward, save, [name + ".weight", name + ".bias"]))
         return y
+
+    def _bn_multi(self, xs, names, relu=True, res=None):
+        """The BatchNorms `names[b]` over `xs[b]` (one per branch, independent) as ONE multi-tensor call per pass
+        (udp_bn_train_fwd_multi / _bwd_multi): results are those of `_bn` per branch, bit for bit."""
+        L = _lib.lib()
+        nb = len(xs)
+        res = res or [None] * nb
+        relus = list(relu) if isinstance(relu, (list, tuple)) else [relu] * nb
+        ys = [self._new(x.n, x.h, x.w, x.c) for x in xs]
+        saves = [torch.empty(2 * x.ck, dtype=torch.float32, device=self.device) for x in xs]
+        items = (_lib.BnItem * nb)()
+        for b, (x, y, sv) in enumerate(zip(xs, ys, saves)):
+            if x.c != x.ck:
+                raise ValueError("%s: BatchNorm over %d channels (not a multiple of 16)" % (names[b], x.c))
+            it = items[b]
+            it.x, it.y, it.m, it.c = x.buf.data_ptr(), y.buf.data_ptr(), x.n * x.h * x.w, x.ck
+            it.gamma, it.beta = self._p(names[b] + ".weight"), self._p(names[b] + ".bias")
+            it.running_mean, it.running_var = self._p(names[b] + ".running_mean"), self._p(names[b] + ".running_var")
+            it.save_mean, it.save_invstd = sv.data_ptr(), sv.data_ptr() + 4 * x.ck
+            it.res = None if res[b] is None else res[b].buf.data_ptr()
+            it.relu, it.rows = int(relus[b]), x.bn_rows
+            it.ws = (x.bn_ws if x.bn_rows else self._bn_wss[b]).data_ptr()
+        _lib.check(L.udp_bn_train_fwd_multi(items, nb, BN_EPS, BN_MOMENTUM, self._dt, self._stream()))
+
+        def backward():
+            bi = (_lib.BnItem * nb)()
+            g_outs = []
+            for b, (x, y, sv) in enumerate(zip(xs, ys, saves)):
+                x.grad = self._like(x)
+                if y.grad is None:                     # a branch output nothing consumed: zero gradient
+                    y.grad = torch.zeros_like(y.buf)
+                g_out = self._like(y) if res[b] is not None and res[b].needs_grad else None
+                g_outs.append(g_out)
+                it = bi[b]
+                it.x, it.dy, it.m, it.c = x.buf.data_ptr(), y.grad.data_ptr(), x.n * x.h * x.w, x.ck
+                it.y_relu = y.buf.data_ptr() if relus[b] else None
+                it.gamma = self._p(names[b] + ".weight")
+                it.save_mean, it.save_invstd = sv.data_ptr(), sv.data_ptr() + 4 * x.ck
+                it.dgamma, it.dbeta = self._g(names[b] + ".weight"), self._g(names[b] + ".bias")
+                it.dx = x.grad.data_ptr()
+                it.g_out = None if g_out is None else g_out.data_ptr()
+                it.ws = self._bn_wss[b].data_ptr()
+            _lib.check(L.udp_bn_train_bwd_multi(bi, nb, self._dt, self._stream()))
+            for b, g_out in enumerate(g_outs):
+                if g_out is None:
+                    continue
+                r = res[b]
+                if r.grad is None:
+                    r.grad = g_out
+                else:
+                    _lib.check(L.udp_ew_accumulate(r.grad.data_ptr(), g_out.data_ptr(), r.n, r.h, r.w, r.ck, 0, 0, 0,
+                                                   self._dt, self._stream()))
+        keys = [n + s for n in names for s in (".weight", ".bias")]
+        self._tape.append((_Group(ys), backward, saves, keys))
+        return ys
+
+    def _blocks_lockstep(self, xs, ps):
+        """BasicBlock `ps[b]` on branch b, all branches at once: the convs stay one launch each, the two BatchNorms
+        of the block run as multi-tensor calls over the branches."""
+        nb = len(xs)
+        c1 = [self._conv(xs[b], ps[b] + ".conv1", bn_stats=True, slot=b) for b in range(nb)]
+        t = self._bn_multi(c1, [q + ".bn1" for q in ps])
+        c2 = [self._conv(t[b], ps[b] + ".conv2", bn_stats=True, slot=b) for b in range(nb)]
+        return self._bn_multi(c2, [q + ".bn2" for q in ps], res=xs)
+
+    def _conv_bn_multi(self, specs):
+        """Independent conv + BatchNorm pairs `(x, conv, bn, stride, relu)`: convs one launch each, their
+        BatchNorms four at a time as multi-tensor calls."""
+        outs = []
+        for c0 in range(0, len(specs), 4):
+            chunk = specs[c0:c0 + 4]
+            if len(chunk) == 1:
+                x, cv, bn, st, relu = chunk[0]
+                outs.append(self._bn(self._conv(x, cv, stride=st, bn_stats=True), bn, relu=relu))
+                continue
+            ys = [self._conv(x, cv, stride=st, bn_stats=True, slot=b) for b, (x, cv, _, st, _) in enumerate(chunk)]
+            outs += self._bn_multi(ys, [bn for _, _, bn, _, _ in chunk], relu=[r for *_, r in chunk])
+        return outs
+
+    def _fuse_lockstep(self, xs, p, last):
+        """The fuse layers of a module (pose_hrnet.py:224-272) level by level: every 1x1 (j > i) conv and the k-th
+        stride-2 conv of every (i, j < i) chain only depend on the level before."""
+        nb = len(xs)
+        n_out = 1 if last else nb
+        ups, cur = {}, {}
+        specs, keys = [], []
+        for i in range(n_out):
+            for j in range(nb):
+                q = "%s.fuse_layers.%d.%d" % (p, i, j)
+                if j > i:
+                    specs.append((xs[j], q + ".0", q + ".1", 1, False))
+                    keys.append(("up", i, j))
+                elif j < i:
+                    specs.append((xs[j], q + ".0.0", q + ".0.1", 2, i - j != 1))
+                    keys.append(("down", i, j))
+        for key, t in zip(keys, self._conv_bn_multi(specs)):
+            (ups if key[0] == "up" else cur)[key[1:]] = t
+        for k in range(1, n_out):
+            todo = [(i, j) for (i, j) in cur if i - j > k]
+            specs = [(cur[(i, j)], "%s.fuse_layers.%d.%d.%d.0" % (p, i, j, k), "%s.fuse_layers.%d.%d.%d.1" % (p, i, j, k), 2,
+                      k != i - j - 1) for i, j in todo]
+            for ij, t in zip(todo, self._conv_bn_multi(specs)):
+                cur[ij] = t
+        outs = []
+        for i in range(n_out):
+            terms = []
+            for j in range(nb):
+                if j > i:
+                    terms.append((ups[(i, j)], j - i))
+                elif j == i:
+                    terms.append((self._conv(xs[j], "%s.fuse_layers.%d.%d.0" % (p, i, j)) if last else xs[j], 0))
+                else:
+                    terms.append((cur[(i, j)], 0))
+            outs.append(self._sum_relu(terms))
+        return outs
 
     def _sum_relu(self, terms):
         """y = relu(sum_k up(term_k, shift_k)): HighResolutionModule.forward :266-272."""
@@ -305,9 +447,15 @@ class HRNetTrainer:
     def _module(self, xs, p, num_blocks, last):
         nb = len(xs)
         xs = list(xs)
-        for b in range(nb):
-            for k in range(num_blocks[b]):
-                xs[b] = self._basic(xs[b], "%s.branches.%d.%d" % (p, b, k))
+        if self.bn_multi and 1 < nb <= 4 and len(set(num_blocks[:nb])) == 1:
+            for k in range(num_blocks[0]):
+                xs = self._blocks_lockstep(xs, ["%s.branches.%d.%d" % (p, b, k) for b in range(nb)])
+        else:
+            for b in range(nb):
+                for k in range(num_blocks[b]):
+                    xs[b] = self._basic(xs[b], "%s.branches.%d.%d" % (p, b, k))
+        if self.bn_multi and nb > 1:
+            return self._fuse_lockstep(xs, p, last)
         outs = []
         for i in range(1 if last else nb):
             terms = []
