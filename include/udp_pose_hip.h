@@ -365,6 +365,13 @@ int udp_nchw_to_nhwc(const float* src, int n, int c, int h, int w, int c_pad, vo
  * The gradient is read as g*grad_scale (1/world_size after a SUM all-reduce; 1 otherwise). */
 int udp_adam_step(float* p, const float* g, float* m, float* v, int64_t count, float lr, float beta1,
                   float beta2, float eps, int step, float grad_scale, void* stream);
+/* The same for a captured training step (hipGraph replay): the two step-dependent scalars
+ * coef = {lr / (1 - beta1^step), 1 / sqrt(1 - beta2^step)} -- exactly the values udp_adam_step uses, as
+ * udp_adam_coefficients computes them on the host -- are read from device memory at run time, so the host only
+ * refreshes those 8 bytes before each replay. */
+int udp_adam_coefficients(float lr, float beta1, float beta2, int step, float* coef_host);
+int udp_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t count, float beta1, float beta2,
+                      float eps, const float* coef_dev, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

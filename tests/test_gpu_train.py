@@ -149,6 +149,89 @@ def test_batchnorm_train_forward_backward(c, h, w, n, relu, with_res):
         np.testing.assert_allclose(gout.cpu().permute(0, 3, 1, 2).numpy(), res.grad.numpy(), atol=1e-6)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_multi_tensor_batchnorm_equals_single_calls(dtype):
+    """udp_bn_train_fwd_multi / _bwd_multi (one launch per pass over the BatchNorms of up to 4 HRNet branches,
+    pose_hrnet.py:253-256) against udp_bn_train_fwd / _bwd per tensor: outputs, saved statistics, running
+    statistics, dx, g_out, dgamma, dbeta -- bit for bit (same block partition, same fixed-order sums)."""
+    L = _lib.lib()
+    dt, tdt = _lib.DTYPES[dtype], (torch.float32 if dtype == "f32" else torch.bfloat16)
+    g = torch.Generator().manual_seed(11)
+    shapes = [(3, 16, 12, 128), (3, 32, 24, 64), (3, 64, 48, 32), (3, 8, 6, 256)]       # the four W32 branches
+    relus, with_res = [1, 0, 1, 1], [True, False, True, False]
+
+    def fresh():
+        ts = []
+        for (n, h, w, c), wr in zip(shapes, with_res):
+            t = dict(m=n * h * w, c=c)
+            t["x"] = (torch.randn(n * h * w, c, generator=g) * 1.5 + 0.3).to(tdt).cuda()
+            t["dy"] = torch.randn(n * h * w, c, generator=g).to(tdt).cuda()
+            t["res"] = torch.randn(n * h * w, c, generator=g).to(tdt).cuda() if wr else None
+            t["gamma"], t["beta"] = (torch.rand(c, generator=g) + 0.5).cuda(), torch.randn(c, generator=g).cuda()
+            ts.append(t)
+        return ts
+    g.manual_seed(11)
+    single = fresh()
+    g.manual_seed(11)
+    multi = fresh()
+    for t in single + multi:
+        c = t["c"]
+        t["rm"], t["rv"] = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
+        t["save"] = torch.empty(2 * c, device="cuda")
+        t["ws"] = torch.zeros(L.udp_bn_workspace_doubles(c), dtype=torch.float64, device="cuda")
+        t["y"], t["dx"], t["gout"] = torch.empty_like(t["x"]), torch.empty_like(t["x"]), torch.empty_like(t["x"])
+        t["dgam"], t["dbet"] = torch.empty(c, device="cuda"), torch.empty(c, device="cuda")
+    for t, relu in zip(single, relus):
+        c = t["c"]
+        _lib.check(L.udp_bn_train_fwd(t["x"].data_ptr(), t["m"], c, t["gamma"].data_ptr(), t["beta"].data_ptr(), 1e-5, 0.1,
+                                      t["rm"].data_ptr(), t["rv"].data_ptr(), t["save"].data_ptr(), t["save"].data_ptr() + 4 * c,
+                                      None if t["res"] is None else t["res"].data_ptr(), relu, t["y"].data_ptr(), dt,
+                                      t["ws"].data_ptr(), _stream()))
+        _lib.check(L.udp_bn_train_bwd(t["x"].data_ptr(), t["dy"].data_ptr(), t["y"].data_ptr() if relu else None, t["m"], c,
+                                      t["gamma"].data_ptr(), t["save"].data_ptr(), t["save"].data_ptr() + 4 * c,
+                                      t["dgam"].data_ptr(), t["dbet"].data_ptr(), t["dx"].data_ptr(), t["gout"].data_ptr(), dt,
+                                      t["ws"].data_ptr(), _stream()))
+    items = (_lib.BnItem * 4)()
+    for it, t, relu in zip(items, multi, relus):
+        c = t["c"]
+        it.x, it.dy, it.y, it.dx, it.g_out = (t[k].data_ptr() for k in ("x", "dy", "y", "dx", "gout"))
+        it.y_relu = t["y"].data_ptr() if relu else None
+        it.res = None if t["res"] is None else t["res"].data_ptr()
+        it.gamma, it.beta, it.running_mean, it.running_var = (t[k].data_ptr() for k in ("gamma", "beta", "rm", "rv"))
+        it.save_mean, it.save_invstd = t["save"].data_ptr(), t["save"].data_ptr() + 4 * c
+        it.dgamma, it.dbeta, it.ws = t["dgam"].data_ptr(), t["dbet"].data_ptr(), t["ws"].data_ptr()
+        it.m, it.c, it.rows, it.relu = t["m"], c, 0, relu
+    _lib.check(L.udp_bn_train_fwd_multi(items, 4, 1e-5, 0.1, dt, _stream()))
+    _lib.check(L.udp_bn_train_bwd_multi(items, 4, dt, _stream()))
+    torch.cuda.synchronize()
+    for a, b in zip(single, multi):
+        for k in ("y", "save", "rm", "rv", "dx", "gout", "dgam", "dbet"):
+            torch.testing.assert_close(a[k].float(), b[k].float(), rtol=0, atol=0, msg=k)
+    with pytest.raises(_lib.UdpPoseError):
+        _lib.check(L.udp_bn_train_fwd_multi(items, 5, 1e-5, 0.1, dt, _stream()))
+
+
+def test_graphed_train_step_equals_eager_steps():
+    """train_step_graphed (step 1 eager, step 2 captured as a hipGraph and replayed, steps 3.. replayed; Adam's
+    step-dependent scalars refreshed in device memory before every replay) against train_step: losses and all
+    parameters bit for bit after eight back-to-back steps on changing batches (losses to the last bits of their fp64 atomic sums)."""
+    cfg = {"MODEL": {"EXTRA": EXTRA, "NUM_JOINTS": 5, "TARGET_TYPE": "gaussian"}}
+    sd0 = synth.synth_state_dict(EXTRA, 5, "gaussian", seed=3)
+    batches = [make_batch("gaussian", n=6, seed=50 + k) for k in range(4)]
+    outs = []
+    for graphed in (False, True):
+        tr = HRNetTrainer(cfg, {k: v.clone() for k, v in sd0.items()}, device="cuda", lr=1e-3)
+        losses = []
+        dev = [(x.cuda(), tg.cuda(), tw.cuda()) for x, tg, tw in batches]
+        for x, tg, tw in dev + dev:                    # no host synchronisation between the steps: the host runs ahead
+            loss = tr.train_step_graphed(x, tg, tw) if graphed else tr.train_step(x, tg, tw)
+            losses.append(loss.clone())
+        outs.append((np.array([l.cpu().numpy() for l in losses]), tr.flat.cpu().numpy().copy(), tr.step_count))
+    assert outs[0][2] == outs[1][2] == 8
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-12)       # the loss VALUE is summed with fp64 atomics
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+
+
 def test_sum_nodes_and_their_gradients():
     """relu(a + up2(b) + up4(c)) forward through udp_ew_accumulate, backward through relu_bwd / upsample_bwd."""
     L = _lib.lib()

@@ -14,6 +14,7 @@ ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--warmup", type=int, default=2)
 ap.add_argument("--dtype", default="f32")
 ap.add_argument("--target", default="gaussian")
+ap.add_argument("--no-graph", action="store_true", help="one ctypes launch per kernel instead of replaying the captured step")
 a = ap.parse_args()
 # one process per GPU under torch.distributed.run (backend nccl = RCCL); plain `python` = one GPU
 world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
@@ -28,8 +29,15 @@ x = torch.from_numpy(synth.synth_crops(a.batch, 256, 192, seed=1 + rank)).cuda()
 c = nj * (3 if a.target == "offset" else 1)
 tg = torch.from_numpy(synth.synth_heatmaps(a.batch, nj, 64, 48, seed=2, channels_per_joint=c // nj)).cuda()
 tw = torch.ones(a.batch, nj, 1, device="cuda")
-for _ in range(a.warmup):
-    loss = tr.train_step(x, tg, tw, world_size=world)
+graphed = world == 1 and not a.no_graph          # the exchange step of N > 1 runs on torch.distributed's stream: eager
+
+
+def step():
+    return tr.train_step_graphed(x, tg, tw) if graphed else tr.train_step(x, tg, tw, world_size=world)
+
+
+for _ in range(max(a.warmup, 2 if graphed else 0)):
+    loss = step()
 torch.cuda.synchronize()
 if world > 1:
     dist.barrier()
@@ -37,7 +45,7 @@ t0 = time.time()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(a.steps):
-    loss = tr.train_step(x, tg, tw, world_size=world)
+    loss = step()
 e1.record()
 torch.cuda.synchronize()
 wall = (time.time() - t0) / a.steps * 1e3
@@ -58,12 +66,13 @@ if rank == 0:
     print(json.dumps({"metric": "images/sec HRNet-W32 256x192 training step (fwd + JointsMSELoss + bwd + Adam"
                                 + (" + gradient all-reduce)" if world > 1 else ")"),
                       "value": round(a.batch * world / wall * 1e3, 1), "unit": "images/s", "n_gpus": world,
-                      "ms_per_step": round(wall, 3), "dtype": a.dtype, "batch_per_gpu": a.batch,
+                      "ms_per_step": round(wall, 3), "dtype": a.dtype, "batch_per_gpu": a.batch, "hipgraph": graphed,
                       "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s",
                                    "frac": round(tf / peak, 4),
                                    "note": "algorithmic FLOPs of the three conv passes per step / device time of the "
                                            "whole step; the step is bound by its many small BatchNorm / element-wise "
                                            "launches, not by the matrix pipe (profiles/r02_train_*_kernel_stats)"}}))
     print("world %d (global batch %d): %.0f img/s" % (world, a.batch * world, a.batch * world / wall * 1e3))
-    print("train W32 b=%d/GPU %s: %.1f ms/step (device %.1f ms), %.0f img/s per GPU, loss %s, peak mem %.1f GiB" % (
-        a.batch, a.dtype, wall, dev, a.batch / wall * 1e3, loss.cpu().numpy(), torch.cuda.max_memory_allocated() / 2**30))
+    print("train W32 b=%d/GPU %s%s: %.1f ms/step (device %.1f ms), %.0f img/s per GPU, loss %s after %d steps, peak mem %.1f GiB" % (
+        a.batch, a.dtype, " hipGraph replay" if graphed else "", wall, dev, a.batch / wall * 1e3, loss.cpu().numpy(), tr.step_count,
+        torch.cuda.max_memory_allocated() / 2**30))

@@ -114,6 +114,8 @@ _SIGS = {
     "udp_nchw_to_nhwc": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
     "udp_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
                                 C.c_float, _P]),
+    "udp_adam_coefficients": (C.c_int, [C.c_float, C.c_float, C.c_float, C.c_int, _P]),
+    "udp_adam_step_dev": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, _P, C.c_float, _P]),
 }
 EXPORTS = tuple(_SIGS)
 

@@ -716,6 +716,22 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// The same with the two step-dependent scalars read from device memory, so that a captured launch (hipGraph
+// replay of the whole training step) follows the step count: coef = {lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t)}
+__global__ __launch_bounds__(256) void adam_kernel_dev(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, long count, float b1, float b2, float eps,
+                                                       const float* __restrict__ coef, float grad_scale) {
+  const float step_size = coef[0], inv_sqrt_bc2 = coef[1];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) {
+    const float gi = grad_scale == 1.f ? g[i] : g[i] * grad_scale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = p[i] - step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+  }
+}
+
 #define UDP_DISPATCH_T(dtype, CALL_F32, CALL_BF16) \
   do {                                             \
     if ((dtype) == UDP_F32) {                      \
@@ -1067,4 +1083,20 @@ extern "C" int udp_adam_step(float* p, const float* g, float* m, float* v, int64
   adam_kernel<<<nblocks(count, 256 * 4), 256, 0, s>>>(p, g, m, v, count, beta1, beta2, eps, (float)((double)lr / bc1),
                                                        (float)(1.0 / sqrt(bc2)), grad_scale);
   return launched("udp_adam_step");
+}
+
+extern "C" int udp_adam_coefficients(float lr, float beta1, float beta2, int step, float* coef_host) {
+  if (!coef_host || step < 1) return fail(UDP_ERR_ARG, "udp_adam_coefficients: argument");
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  coef_host[0] = (float)((double)lr / bc1);
+  coef_host[1] = (float)(1.0 / sqrt(bc2));
+  return UDP_OK;
+}
+
+extern "C" int udp_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t count, float beta1, float beta2,
+                                 float eps, const float* coef_dev, float grad_scale, void* stream) {
+  if (!p || !g || !m || !v || !coef_dev || count <= 0) return fail(UDP_ERR_ARG, "udp_adam_step_dev: argument");
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  adam_kernel_dev<<<nblocks(count, 256 * 4), 256, 0, s>>>(p, g, m, v, count, beta1, beta2, eps, coef_dev, grad_scale);
+  return launched("udp_adam_step_dev");
 }

@@ -12,6 +12,8 @@
   :212-221 does and hands them to ``val_dataset.evaluate`` when the dataset has one.
 Logging / tensorboard / debug images of the reference are out of scope.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -170,8 +172,11 @@ def train(config, train_loader, model, criterion, optimizer, epoch=0, output_dir
         trainer.lr, trainer.betas, trainer.eps = _adam_hyper(optimizer)
         tw = target_weight.to(trainer.device, non_blocking=True) if use_tw else \
             torch.ones(n, trainer.num_joints, 1, dtype=torch.float32, device=trainer.device)
-        loss = trainer.train_step(input.to(trainer.device, non_blocking=True).contiguous(),
-                                  target.to(trainer.device, non_blocking=True), tw, world_size=world_size)
+        x, tg = input.to(trainer.device, non_blocking=True).contiguous(), target.to(trainer.device, non_blocking=True)
+        if world_size == 1 and os.environ.get("UDP_POSE_NO_TRAIN_GRAPH") is None:
+            loss = trainer.train_step_graphed(x, tg, tw)             # the step replayed as a hipGraph (same results)
+        else:
+            loss = trainer.train_step(x, tg, tw, world_size=world_size)
         if not isinstance(model, HRNetTrainer):
             model._stale = True
         total += loss * n

@@ -124,6 +124,7 @@ class HRNetTrainer:
         self._bn_ws = self._bn_wss[0]
         self.bn_multi = os.environ.get("UDP_POSE_NO_BN_MULTI") is None           # A/B knob
         self._loss = torch.zeros(2, dtype=torch.float64, device=self.device)
+        self._graphs, self._warm, self._coef = {}, set(), None            # train_step_graphed
         self._tape = []
         self.fuse_bn_stats = os.environ.get("UDP_POSE_NO_BN_FUSION") is None     # A/B knob
         # gradient buckets for the all-reduce (~25 MB each): consecutive parameters of the flat
@@ -560,6 +561,7 @@ class HRNetTrainer:
         _lib.check(_lib.lib().udp_mse_loss(heat.data_ptr(), target.data_ptr(), target_weight.data_ptr(), b, j,
                                            heat.shape[2] * heat.shape[3], int(off), self._loss.data_ptr(), d.data_ptr(),
                                            self._stream()))
+        self._loss_grad = d
         return self._loss, d
 
     def adam_step(self, grad_scale=1.0):
@@ -570,6 +572,59 @@ class HRNetTrainer:
                                             self.exp_avg_sq.data_ptr(), self._n_param, self.lr, self.betas[0],
                                             self.betas[1], self.eps, self.step_count, float(grad_scale),
                                             self._stream()))
+
+    def _adam_step_dev(self):
+        _lib.check(_lib.lib().udp_adam_step_dev(self.flat.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(),
+                                                self.exp_avg_sq.data_ptr(), self._n_param, self.betas[0], self.betas[1],
+                                                self.eps, self._coef.data_ptr(), 1.0, self._stream()))
+
+    def train_step_graphed(self, x, target, target_weight):
+        """train_step for one GPU with the whole step (weight packing, forward, criterion, backward, Adam: ~1900
+        launches issued from the Python tape) captured ONCE per input shape as a hipGraph (torch.cuda.graph: stream
+        capture of our launches on torch's capture stream, activations from the graph's private pool) and replayed:
+        the host then costs one graph launch per step instead of one ctypes call per kernel.  The first step of a
+        shape runs eagerly (lazy one-time initialisation must not be captured), the second captures and replays.
+        Arithmetic and results are those of train_step, bit for bit; the learning rate may change between steps
+        (it only enters through Adam's two scalars, uploaded before every replay), betas / eps are part of the key.
+        At most two shapes stay captured (a full and a ragged last batch)."""
+        key = (tuple(x.shape), tuple(target.shape), tuple(target_weight.shape), self.betas, self.eps)
+        ent = self._graphs.get(key)
+        if ent is None:
+            if key not in self._warm:                                # first step of this shape: eager
+                self._warm.add(key)
+                return self.train_step(x, target, target_weight)
+            if self._coef is None:
+                self._coef = torch.zeros(2, dtype=torch.float32, device=self.device)
+                # pinned staging slots for the asynchronous upload of Adam's two scalars: the host runs steps ahead
+                # of the GPU, a slot is rewritten only after the copy that read it has completed (its event)
+                self._coef_host = [torch.zeros(2, dtype=torch.float32).pin_memory() for _ in range(4)]
+                self._coef_done = [None] * 4
+            gx, gt, gw = x.clone(), target.contiguous().clone(), target_weight.contiguous().clone()
+            while len(self._graphs) >= 2:
+                self._graphs.pop(next(iter(self._graphs)))
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                heat = self.forward(gx)
+                self.loss_and_grad(heat, gt, gw)
+                self.backward(self._loss_grad)
+                self._adam_step_dev()
+            ent = self._graphs[key] = (graph, gx, gt, gw)
+        graph, gx, gt, gw = ent
+        gx.copy_(x, non_blocking=True)
+        gt.copy_(target, non_blocking=True)
+        gw.copy_(target_weight, non_blocking=True)
+        self.step_count += 1
+        slot = self.step_count % 4
+        if self._coef_done[slot] is not None:
+            self._coef_done[slot].synchronize()
+        _lib.check(_lib.lib().udp_adam_coefficients(self.lr, self.betas[0], self.betas[1], self.step_count,
+                                                    self._coef_host[slot].data_ptr()))
+        self._coef.copy_(self._coef_host[slot], non_blocking=True)
+        self._coef_done[slot] = torch.cuda.Event()
+        self._coef_done[slot].record()
+        graph.replay()
+        return self._loss
 
     def train_step(self, x, target, target_weight, world_size=1):
         """function.py:46-76 for one batch.  Returns the loss tensor fp64 [2] = (L_hm, L_offset) on device."""
