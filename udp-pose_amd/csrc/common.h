@@ -68,6 +68,7 @@ struct ConvMulti {
   ConvParams p[4];
   unsigned start[5];      // first flat block of sub-problem j; unused entries 0xFFFFFFFF, start[4] = total
   unsigned tiles[4];      // tiles (grid.x) of sub-problem j
+  unsigned ncby[4];       // conv_ws_multi: cout blocks (grid.y) of sub-problem j
   int code[4];            // conv_ws_multi: cout pairs per workgroup (CP) of sub-problem j
   // conv_ws_multi dispatch order: the grid is a sequence of segments, segment s = workgroups seg_first[s] ..
   // of member seg_mem[s], placed at flat blocks seg_start[s] .. seg_start[s + 1] - 1 (unused: 0xFFFFFFFF)

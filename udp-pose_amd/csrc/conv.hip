@@ -962,9 +962,37 @@ __device__ __forceinline__ void conv_ws_body(const ConvParams& p, const int tile
 #endif
 }
 
+// Flat workgroup index of a conv -> (tile, cout block).  The cout blocks of one pixel tile stage the same input
+// tile: they are placed 8 workgroups apart -- same XCD (workgroup i runs on XCD i % 8), started together -- so the
+// second read of the tile hits that XCD's L2 instead of HBM: groups of 8 tiles x all cout blocks, cout-block-major
+// inside the group (the last ntiles % 8 tiles form a smaller group).  Wave-uniform.
+__device__ __forceinline__ void ws_decode(unsigned b, unsigned ntiles, unsigned nc, int& tile, int& cby) {
+  if (nc == 1) {
+    tile = (int)b;
+    cby = 0;
+    return;
+  }
+  const unsigned full = (ntiles >> 3) * 8u * nc;
+  unsigned base = 0, width = 8, r = b;
+  if (b < full) {
+    const unsigned g = b / (8u * nc);
+    r = b - g * 8u * nc;
+    base = g * 8u;
+  } else {
+    r = b - full;
+    base = (ntiles >> 3) * 8u;
+    width = ntiles & 7u;
+  }
+  const unsigned c = r / width;
+  cby = (int)c;
+  tile = (int)(base + r - c * width);
+}
+
 template <int KS, int STRIDE, int PB, int CP, bool NCHW>
 __global__ __launch_bounds__(256, 2) void conv_ws_h2_kernel(const ConvParams p) {
-  conv_ws_body<KS, STRIDE, PB, CP, NCHW>(p, blockIdx.x, blockIdx.y);
+  int tile, cby;
+  ws_decode(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x, gridDim.y, tile, cby);   // dispatch order = flat index
+  conv_ws_body<KS, STRIDE, PB, CP, NCHW>(p, tile, cby);
 }
 
 // Merged launch of up to 4 independent weight-stationary convs (same-depth convs of different HRNet branches):
@@ -979,8 +1007,10 @@ __global__ __launch_bounds__(256, 2) void conv_ws_multi(const ConvMulti m) {
   // would wrap every weight load of the body in a waterfall loop)
   const int j = __builtin_amdgcn_readfirstlane(m.seg_mem[sg]);
   const unsigned r = __builtin_amdgcn_readfirstlane(b - m.seg_start[sg] + m.seg_first[sg]);
-  const unsigned cby = __builtin_amdgcn_readfirstlane(r / m.tiles[j]);
-  const int tile = (int)(r - cby * m.tiles[j]);
+  int tile, cby;
+  ws_decode(r, m.tiles[j], m.ncby[j], tile, cby);
+  tile = __builtin_amdgcn_readfirstlane(tile);
+  cby = __builtin_amdgcn_readfirstlane(cby);
   switch (m.code[j]) {
     case 1: conv_ws_body<KS, 1, 6, 1, false>(m.p[j], tile, (int)cby); break;
     case 2: conv_ws_body<KS, 1, 6, 2, false>(m.p[j], tile, (int)cby); break;
@@ -2339,12 +2369,13 @@ int describe_multi(const Launch* members, int n, ConvMulti* m, Launch* out) {
       m->p[j] = members[j].p;
       m->start[j] = total;
       m->tiles[j] = members[j].grid.x;
+      m->ncby[j] = members[j].grid.y;
       m->code[j] = members[j].ws_cp;
       total += members[j].grid.x * members[j].grid.y;
       if (members[j].lds > lds) lds = members[j].lds;
     }
     for (int j = n; j < 5; ++j) m->start[j] = j < 4 ? 0xFFFFFFFFu : total;
-    for (int j = n; j < 4; ++j) m->tiles[j] = 1;
+    for (int j = n; j < 4; ++j) m->tiles[j] = m->ncby[j] = 1;
     ws_order(m, n);
     out->fn = wk[members[0].groupable / 10 % 10 == 3 ? 0 : 1];
     out->grid = dim3(total);
