@@ -293,6 +293,24 @@ size_t udp_conv2d_wgrad_workspace_bytes(int cout, int cin, int ks);
 int udp_conv2d_wgrad(const void* x, const void* dy, int n, int hin, int win, int cin_k, int hout,
                      int wout, int cout_k, int ks, int stride, int cout, int cin, int dtype, float* dw,
                      int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* Up to 4 independent plain convs (same dtype and batch n) in as few launches as possible -- the same-depth convs
+ * of the HRNet branches in the training step (pose_hrnet.py:253-256): members whose tile fits the merged kernel run
+ * as ONE launch, the rest on their own; per-member results are those of udp_conv2d_fused / udp_conv2d_fused_bn.
+ * res (optional) is accumulated as in udp_conv2d_fused; bn_ws != NULL (then no res / ReLU): BatchNorm partial rows
+ * as udp_conv2d_fused_bn leaves them, their count in bn_rows. */
+typedef struct udp_conv_item {
+  const udp_conv_op* op;
+  const void* in;
+  const void* weights;
+  const float* bias;
+  const void* res;
+  void* out;
+  double* bn_ws;
+  size_t bn_ws_doubles;
+  int32_t bn_rows;     /* out */
+  int32_t reserved;
+} udp_conv_item;
+int udp_conv2d_fused_group(udp_conv_item* items, int n_items, int dtype, int n, void* stream);
 /* nn.BatchNorm2d in train mode over x [m = N*H*W rows][c]: batch mean / biased variance (fp64 sums),
  * running_mean/var <- (1-momentum)*running + momentum*batch (unbiased variance), either may be NULL;
  * y = [relu](xhat*gamma + beta [+ res]).  save_mean / save_invstd fp32 [c] feed the backward.

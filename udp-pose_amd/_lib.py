@@ -27,6 +27,13 @@ class BnItem(C.Structure):
         ("m", C.c_int64), ("c", C.c_int32), ("rows", C.c_int32), ("relu", C.c_int32), ("reserved", C.c_int32)]
 
 
+class ConvItem(C.Structure):
+    """struct udp_conv_item (include/udp_pose_hip.h): one member of udp_conv2d_fused_group."""
+    _fields_ = [("op", C.c_void_p), ("inp", C.c_void_p), ("weights", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p),
+                ("out", C.c_void_p), ("bn_ws", C.c_void_p), ("bn_ws_doubles", C.c_size_t), ("bn_rows", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
 class ConvOp(C.Structure):
     """struct udp_conv_op (include/udp_pose_hip.h)."""
     _fields_ = [
@@ -104,6 +111,7 @@ _SIGS = {
     "udp_bn_train_fwd_from_sums": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P, _P,
                                              C.c_int, _P, C.c_int, _P, C.c_int, _P]),
     "udp_bn_train_bwd": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
+    "udp_conv2d_fused_group": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     "udp_bn_train_fwd_multi": (C.c_int, [_P, C.c_int, C.c_float, C.c_float, C.c_int, _P]),
     "udp_bn_train_bwd_multi": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "udp_ew_accumulate": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -564,9 +564,10 @@ extern "C" int udp_conv2d_fused_bn(const udp_conv_op* o, int dtype, int n, const
   return conv2d_fused_impl(o, dtype, n, in, weights, bias, nullptr, nullptr, nullptr, nullptr, out, bn_ws, bn_ws_doubles, bn_rows, stream);
 }
 
-static int conv2d_fused_impl(const udp_conv_op* o, int dtype, int n, const void* in, const void* weights,
-                             const float* bias, const void* res, const void* up0, const void* up1,
-                             const void* up2, void* out, double* bn_ws, size_t bn_ws_doubles, int* bn_rows, void* stream) {
+static int conv2d_params(const udp_conv_op* o, int dtype, int n, const void* in, const void* weights,
+                         const float* bias, const void* res, const void* up0, const void* up1,
+                         const void* up2, void* out, ConvParams* pp) {
+  ConvParams& p = *pp;
   if (!o || !in || !out) return fail(UDP_ERR_ARG, "udp_conv2d_fused: null pointer");
   if (dtype != UDP_F32 && dtype != UDP_BF16 && dtype != UDP_F16X2) return fail(UDP_ERR_ARG, "udp_conv2d_fused: dtype %d", dtype);
   if (n <= 0) return fail(UDP_ERR_ARG, "udp_conv2d_fused: n=%d", n);
@@ -581,7 +582,6 @@ static int conv2d_fused_impl(const udp_conv_op* o, int dtype, int n, const void*
       return fail(UDP_ERR_ARG, "udp_conv2d_fused: output size does not match input/stride");
   }
   const void* ups[3] = {up0, up1, up2};
-  ConvParams p;
   memset(&p, 0, sizeof(p));
   p.N = n;
   p.Hin = o->hin;
@@ -614,6 +614,15 @@ static int conv2d_fused_impl(const udp_conv_op* o, int dtype, int n, const void*
     p.up[u] = ups[u];
     p.up_shift[u] = s;
   }
+  return UDP_OK;
+}
+
+static int conv2d_fused_impl(const udp_conv_op* o, int dtype, int n, const void* in, const void* weights,
+                             const float* bias, const void* res, const void* up0, const void* up1,
+                             const void* up2, void* out, double* bn_ws, size_t bn_ws_doubles, int* bn_rows, void* stream) {
+  ConvParams p;
+  const int prc = conv2d_params(o, dtype, n, in, weights, bias, res, up0, up1, up2, out, &p);
+  if (prc) return prc;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   Launch l;
   p.bn_ws = bn_ws;
@@ -626,4 +635,61 @@ static int conv2d_fused_impl(const udp_conv_op* o, int dtype, int n, const void*
     *bn_rows = (int)l.grid.x;
   }
   return run_launch(l, s);
+}
+
+// Up to 4 independent plain convs (same dtype and batch; the same-depth convs of different HRNet branches in the
+// training step) in as few launches as possible: members whose tile fits the merged instantiation go into ONE
+// conv_mfma_multi launch, the others run on their own.  Per-member results are those of udp_conv2d_fused /
+// udp_conv2d_fused_bn (the K loop order does not depend on the tiling).
+extern "C" int udp_conv2d_fused_group(udp_conv_item* items, int n_items, int dtype, int n, void* stream) {
+  if (!items || n_items < 1 || n_items > 4) return fail(UDP_ERR_ARG, "udp_conv2d_fused_group: %d members (1..4)", n_items);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  std::vector<Launch> L((size_t)n_items);
+  for (int j = 0; j < n_items; ++j) {
+    udp_conv_item& it = items[j];
+    const udp_conv_op* o = it.op;
+    if (!o || o->kind != UDP_OP_CONV || o->n_up || o->out_buf == UDP_BUF_OUTPUT)
+      return fail(UDP_ERR_UNSUPPORTED, "udp_conv2d_fused_group: member %d is not a plain NHWC conv", j);
+    if (it.bn_ws && (dtype == UDP_F16X2 || o->relu || it.res || (o->out_pitch && o->out_pitch != o->cout) || o->out_coff))
+      return fail(UDP_ERR_UNSUPPORTED, "udp_conv2d_fused_group: member %d: BatchNorm sums need a plain fp32 / bf16 conv", j);
+    ConvParams p;
+    int rc = conv2d_params(o, dtype, n, it.in, it.weights, it.bias, it.res, nullptr, nullptr, nullptr, it.out, &p);
+    if (rc) return rc;
+    p.bn_ws = it.bn_ws;
+    rc = n_items > 1 && getenv("UDP_POSE_NO_GROUPS") == nullptr ? describe_conv_grouped(p, dtype, o->ks, o->stride, &L[j]) : 1;
+    if (rc == 1) rc = describe_conv(p, dtype, o->ks, o->stride, &L[j]);
+    if (rc) return rc;
+    if (it.bn_ws) {
+      if ((size_t)L[j].grid.x * 2 * o->cout > it.bn_ws_doubles)
+        return fail(UDP_ERR_WORKSPACE, "udp_conv2d_fused_group: member %d: %u partial rows x %d doubles exceed the workspace", j, L[j].grid.x, 2 * o->cout);
+      it.bn_rows = (int)L[j].grid.x;
+    }
+  }
+  // merged members first (order inside a merged launch: as given, the caller lists the deepest-K member first)
+  std::vector<Launch> G;
+  std::vector<int> rest;
+  for (int j = 0; j < n_items; ++j) {
+    if (L[j].groupable && (G.empty() || L[j].groupable / 10 == G[0].groupable / 10))
+      G.push_back(L[j]);
+    else
+      rest.push_back(j);
+  }
+  if (G.size() >= 2) {
+    ConvMulti m;
+    Launch ml;
+    const int rc = describe_multi(G.data(), (int)G.size(), &m, &ml);
+    if (rc) return rc;
+    void* args[] = {&m};
+    UDP_HIP_CHECK(hipLaunchKernel(ml.fn, ml.grid, ml.block, args, ml.lds, s));
+  } else {
+    for (const Launch& l : G) {
+      const int rc = run_launch(l, s);
+      if (rc) return rc;
+    }
+  }
+  for (int j : rest) {
+    const int rc = run_launch(L[j], s);
+    if (rc) return rc;
+  }
+  return UDP_OK;
 }

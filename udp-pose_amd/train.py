@@ -123,6 +123,7 @@ class HRNetTrainer:
                         for _ in range(4)]
         self._bn_ws = self._bn_wss[0]
         self.bn_multi = os.environ.get("UDP_POSE_NO_BN_MULTI") is None           # A/B knob
+        self.conv_multi = os.environ.get("UDP_POSE_NO_CONV_MULTI") is None       # A/B knob (merged branch convs)
         self._loss = torch.zeros(2, dtype=torch.float64, device=self.device)
         self._graphs, self._warm, self._coef = {}, set(), None            # train_step_graphed
         self._tape = []
@@ -344,13 +345,71 @@ class HRNetTrainer:
         self._tape.append((_Group(ys), backward, saves, keys))
         return ys
 
+    def _convs_lockstep(self, xs, names):
+        """The stride-1 convs `names[b]` on `xs[b]` (one per branch, independent; each followed by a BatchNorm) through
+        udp_conv2d_fused_group: the members whose tile fits the merged kernel run as ONE launch, forward and input
+        gradient alike (bf16 storage; fp32 members run one launch each).  Per-member results equal `_conv`'s."""
+        L = _lib.lib()
+        nb = len(xs)
+        if not self.conv_multi:
+            return [self._conv(xs[b], names[b], bn_stats=True, slot=b) for b in range(nb)]
+        metas = [self._convs[nm] for nm in names]                  # (cout, cin, ks, wf, wd)
+        ys, ops = [], []
+        for x, (cout, cin, ks, wf, wd) in zip(xs, metas):
+            if x.c != cin:
+                raise ValueError("conv expects %d input channels, got %d" % (cin, x.c))
+            y = self._new(x.n, x.h, x.w, cout)
+            ys.append(y)
+            ops.append(self._conv_op(ks, 1, x.ck, y.ck, x.h, x.w, x.h, x.w))
+        order = list(reversed(range(nb)))                          # deepest-K member first in a merged launch
+        items = (_lib.ConvItem * nb)()
+        for it, b in zip(items, order):
+            x, y, (cout, cin, ks, wf, wd) = xs[b], ys[b], metas[b]
+            it.op, it.inp, it.weights = C.addressof(ops[b]), x.buf.data_ptr(), wf.data_ptr()
+            it.bias, it.res, it.out = self._zeros.data_ptr(), None, y.buf.data_ptr()
+            if self.fuse_bn_stats and y.c == y.ck:
+                it.bn_ws, it.bn_ws_doubles = self._bn_wss[b].data_ptr(), self._bn_wss[b].numel()
+        rc = L.udp_conv2d_fused_group(items, nb, self._dt, xs[0].n, self._stream())
+        if rc == -4:           # UDP_ERR_WORKSPACE (more tiles than partial rows fit): the per-conv path sorts it out
+            return [self._conv(xs[b], names[b], bn_stats=True, slot=b) for b in range(nb)]
+        _lib.check(rc)
+        for it, b in zip(items, order):
+            if it.bn_ws:
+                ys[b].bn_rows, ys[b].bn_ws = it.bn_rows, self._bn_wss[b]
+
+        def backward():
+            gi = (_lib.ConvItem * nb)()
+            dops, k = [], 0
+            for b in order:
+                x, y, (cout, cin, ks, wf, wd) = xs[b], ys[b], metas[b]
+                if y.grad is None:
+                    y.grad = torch.zeros_like(y.buf)
+                _lib.check(L.udp_conv2d_wgrad(x.buf.data_ptr(), y.grad.data_ptr(), x.n, x.h, x.w, x.ck, x.h, x.w, y.ck, ks,
+                                              1, cout, cin, self._dt, self._g(names[b] + ".weight"), 0,
+                                              self._wgrad_ws.data_ptr(), self._wgrad_ws.numel(), self._stream()))
+                if not x.needs_grad:
+                    continue
+                res = x.grad
+                if res is None:
+                    x.grad = self._like(x)
+                dops.append(self._conv_op(ks, 1, y.ck, x.ck, x.h, x.w, x.h, x.w))
+                it = gi[k]
+                k += 1
+                it.op, it.inp, it.weights = C.addressof(dops[-1]), y.grad.data_ptr(), wd.data_ptr()
+                it.bias, it.out = self._zeros.data_ptr(), x.grad.data_ptr()
+                it.res = None if res is None else res.data_ptr()
+            if k:
+                _lib.check(L.udp_conv2d_fused_group(gi, k, self._dt, xs[0].n, self._stream()))
+        self._tape.append((_Group(ys), backward, ops, [nm + ".weight" for nm in names]))
+        return ys
+
     def _blocks_lockstep(self, xs, ps):
         """BasicBlock `ps[b]` on branch b, all branches at once: the convs stay one launch each, the two BatchNorms
         of the block run as multi-tensor calls over the branches."""
         nb = len(xs)
-        c1 = [self._conv(xs[b], ps[b] + ".conv1", bn_stats=True, slot=b) for b in range(nb)]
+        c1 = self._convs_lockstep(xs, [q + ".conv1" for q in ps])
         t = self._bn_multi(c1, [q + ".bn1" for q in ps])
-        c2 = [self._conv(t[b], ps[b] + ".conv2", bn_stats=True, slot=b) for b in range(nb)]
+        c2 = self._convs_lockstep(t, [q + ".conv2" for q in ps])
         return self._bn_multi(c2, [q + ".bn2" for q in ps], res=xs)
 
     def _conv_bn_multi(self, specs):
