@@ -403,6 +403,61 @@ def test_conv_epilogue_batchnorm_statistics(ks, stride, cin, cout, h, w, n, dtyp
         torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_grouped_conv_launch_equals_single_launches(dtype):
+    """udp_conv2d_fused_group over the same-depth 3x3 convs of the four W32 branches (pose_hrnet.py:253-256;
+    bf16: ONE merged launch, fp32: one launch each), forward with BatchNorm partial rows and input-gradient form
+    (residual accumulate): outputs bit-identical to udp_conv2d_fused, partial rows add up to the output's sums."""
+    L = _lib.lib()
+    dt, tdt = _lib.DTYPES[dtype], (torch.bfloat16 if dtype == "bf16" else torch.float32)
+    esz = 2 if dtype == "bf16" else 4
+    g = torch.Generator().manual_seed(23)
+    n = 6
+    shapes = [(256, 8, 6), (128, 16, 12), (64, 32, 24), (32, 64, 48)]        # deepest-K member first
+    mem = []
+    for c, h, w in shapes:
+        x = (torch.randn(n, h, w, c, generator=g) + 0.3).to(tdt).cuda()
+        wt = torch.randn(c, c, 3, 3, generator=g).cuda() / np.sqrt(c * 9)
+        wf = torch.empty(9 * c * c * esz, dtype=torch.uint8, device="cuda")
+        _lib.check(L.udp_pack_conv_weights(wt.data_ptr(), c, c, 3, dt, wf.data_ptr(), None, _stream()))
+        op = _lib.ConvOp()
+        op.kind, op.ks, op.stride, op.relu = _lib.UDP_OP_CONV, 3, 1, 0
+        op.cin, op.cout, op.cout_pad = c, c, c
+        op.hin, op.win, op.hout, op.wout = h, w, h, w
+        op.in_buf = op.res_buf = _lib.UDP_BUF_NONE
+        res = torch.randn(n, h, w, c, generator=g).to(tdt).cuda()
+        mem.append(dict(x=x, wf=wf, op=op, res=res, c=c, zeros=torch.zeros(c, device="cuda"),
+                        ws=torch.full((L.udp_bn_workspace_doubles(c),), float("nan"), dtype=torch.float64, device="cuda")))
+    for with_res in (False, True):
+        items = (_lib.ConvItem * 4)()
+        outs = []
+        for it, t in zip(items, mem):
+            y0, y1 = torch.empty_like(t["x"]), torch.empty_like(t["x"])
+            r = t["res"] if with_res else None
+            _lib.check(L.udp_conv2d_fused(C.byref(t["op"]), dt, n, t["x"].data_ptr(), t["wf"].data_ptr(), t["zeros"].data_ptr(),
+                                          None if r is None else r.data_ptr(), None, None, None, y0.data_ptr(), _stream()))
+            it.op, it.inp, it.weights, it.bias = C.addressof(t["op"]), t["x"].data_ptr(), t["wf"].data_ptr(), t["zeros"].data_ptr()
+            it.res, it.out = (None if r is None else r.data_ptr()), y1.data_ptr()
+            if not with_res:
+                it.bn_ws, it.bn_ws_doubles = t["ws"].data_ptr(), t["ws"].numel()
+            outs.append((y0, y1))
+        _lib.check(L.udp_conv2d_fused_group(items, 4, dt, n, _stream()))
+        torch.cuda.synchronize()
+        for it, t, (y0, y1) in zip(items, mem, outs):
+            assert torch.equal(y0, y1)
+            if not with_res:
+                c = t["c"]
+                assert 0 < it.bn_rows <= L.udp_bn_rows_max()
+                part = t["ws"][:it.bn_rows * 2 * c].view(it.bn_rows, 2, c).sum(0).cpu().numpy()
+                yd = y1.double().reshape(-1, c)
+                np.testing.assert_allclose(part[0], yd.sum(0).cpu().numpy(), rtol=1e-12, atol=1e-9)
+                np.testing.assert_allclose(part[1], (yd * yd).sum(0).cpu().numpy(), rtol=1e-12, atol=1e-9)
+    items[0].res = mem[0]["res"].data_ptr()
+    items[0].bn_ws = mem[0]["ws"].data_ptr()
+    with pytest.raises(_lib.UdpPoseError):               # BatchNorm rows of a conv with a residual: refused
+        _lib.check(L.udp_conv2d_fused_group(items, 4, dt, n, _stream()))
+
+
 def test_w32_train_step_at_config3_size(golden_dir):
     """BASELINE config 3 at its own per-GPU size: pose_hrnet_w32 256x192, JointsMSELoss, 32 images.  One
     train_step (fp32) against the CPU oracle's train-mode forward + criterion + autograd (oracle/train.py =
