@@ -2282,7 +2282,7 @@ int describe_conv_grouped(ConvParams p, int dtype, int ks, int stride, Launch* o
 // (longest first) leaves the second half of the launch to the shallow member alone -- HBM-bound at ~4.9 TB/s while
 // the matrix pipe idles, after a first half in which HBM idles (in-kernel timeline, tools/stamp_multi.py).  So the
 // grid alternates chunks of the deep members (list A, longest first) with chunks of the shallowest member (list
-// B), in the proportion that exhausts both lists together: every CU holds both kinds for the whole launch, the
+// B), in about the proportion that exhausts both lists together: every CU holds both kinds for the whole launch, the
 // deepest workgroups still all start in the first round, and the last workgroups to start are short ones.
 // Chunks are multiples of 8 workgroups (one per XCD -- workgroup i runs on XCD i % 8, an uneven pattern would
 // leave some XCDs with all the long workgroups).  UDP_POSE_WS_ORDER=lpt keeps the plain member-after-member order.
@@ -2316,9 +2316,12 @@ static void ws_order(ConvMulti* m, int n) {
     const unsigned nb = hi[n - 1];
     const unsigned na = total - nb;
     unsigned ta = 0, tb = 0;                 // taken from A / B so far
+    // list A runs 25 % ahead of its share, so the deep members are exhausted first and the launch ends on the short
+    // workgroups of B alone (tail = one 15 us workgroup instead of a 20-25 us one): +2 % (UDP_POSE_WS_BIAS, percent)
+    const unsigned bias = getenv("UDP_POSE_WS_BIAS") ? (unsigned)atoi(getenv("UDP_POSE_WS_BIAS")) : 125u;
     while (ta < na && tb < nb && ns < kMultiSegs - n) {
       // the list that is behind its share goes next (ties: A, so that the deepest workgroups lead the grid)
-      if ((unsigned long long)ta * nb <= (unsigned long long)tb * na) {
+      if ((unsigned long long)ta * nb * 100ull <= (unsigned long long)tb * na * bias) {
         int j = 0;
         while (lo[j] == hi[j]) ++j;
         const unsigned c = hi[j] - lo[j] < g ? hi[j] - lo[j] : g;
