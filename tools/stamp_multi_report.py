@@ -1,27 +1,26 @@
 #!/usr/bin/env python3
-"""Offline report of a tools/stamp_multi.py dump: python tools/stamp_multi_report.py dump.npy n0,n1,.. [SEQ]
-n_j = workgroups of member j (deepest first); SEQ = the UDP_POSE_WS_SEQ the dump was taken with."""
+"""Offline report of a tools/stamp_multi.py dump: python tools/stamp_multi_report.py dump.npy n0,n1,.. [lpt]
+n_j = workgroups of member j (deepest first); third argument "lpt" if the dump was taken with UDP_POSE_WS_ORDER=lpt."""
 import collections, sys
 import numpy as np
 F = 2400.0   # s_memtime ticks per us on gfx950 (shader clock while the launch runs)
 
-def order(counts, seq):
-    lo = [0] * len(counts); segs = []
+def order(counts, mode, bias=125, segs_max=64):
+    """Member of every flat workgroup: port of ws_order (csrc/conv.hip).  mode "lpt": member after member."""
+    n = len(counts); lo = [0] * n; segs = []; total = sum(counts)
     def take(j, c):
         c = min(c, counts[j] - lo[j])
         if c: segs.append((j, lo[j], c)); lo[j] += c
-    toks = [t for t in (seq or "").split(",") if t]
-    i = 0
-    while toks and len(segs) < 64 - len(counts):
-        t = toks[i % len(toks)] if "*" in toks else (toks[i] if i < len(toks) else None)
-        if t is None: break
-        i += 1
-        if t == "*": continue
-        side, c = t[0], int(t[1:])
-        live = [k for k in range(len(counts)) if lo[k] < counts[k]]
-        if not live: break
-        take(live[0] if side == "A" else live[-1], c)
-    for j in range(len(counts)): take(j, counts[j])
+    if mode != "lpt":
+        g = 32
+        while (total + g - 1) // g > segs_max - 2 * n: g += 8
+        nb_, na = counts[-1], total - counts[-1]; ta = tb = 0
+        while ta < na and tb < nb_ and len(segs) < segs_max - n:
+            if ta * nb_ * 100 <= tb * na * bias:
+                j = next(k for k in range(n) if lo[k] < counts[k]); c = min(counts[j] - lo[j], g); take(j, c); ta += c
+            else:
+                c = min(nb_ - tb, g); take(n - 1, c); tb += c
+    for j in range(n): take(j, counts[j])
     mem = []
     for j, f, c in segs: mem += [j] * c
     return np.array(mem), segs

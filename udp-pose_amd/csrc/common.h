@@ -64,6 +64,7 @@ struct ConvParams {
 // Kernel argument of conv_mfma_multi: up to 4 independent convs in one launch (flat block index ->
 // sub-problem j, tile, cout block).
 constexpr int kMultiSegs = 64;
+constexpr int kMultiTab = 480;
 struct ConvMulti {
   ConvParams p[4];
   unsigned start[5];      // first flat block of sub-problem j; unused entries 0xFFFFFFFF, start[4] = total
@@ -75,6 +76,12 @@ struct ConvMulti {
   unsigned seg_start[kMultiSegs];
   unsigned seg_first[kMultiSegs];
   int seg_mem[kMultiSegs];
+  // the same order resolved per run of 8 workgroups, when every boundary is a multiple of 8: tab[b >> 3] =
+  // member | cout block << 2 | first tile << 8, workgroup b takes tile (tab >> 8) + (b & 7).  ONE scalar load whose
+  // address only needs blockIdx, instead of the table search + three dependent loads (1.6 us of every workgroup's
+  // 15-60 us, tools/stamp_multi.py).  tab_n == 0: search the segment table.
+  unsigned tab_n;
+  unsigned tab[kMultiTab];
 };
 
 }  // namespace udp

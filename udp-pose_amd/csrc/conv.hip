@@ -966,7 +966,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvParams& p, const int tile
 // tile: they are placed 8 workgroups apart -- same XCD (workgroup i runs on XCD i % 8), started together -- so the
 // second read of the tile hits that XCD's L2 instead of HBM: groups of 8 tiles x all cout blocks, cout-block-major
 // inside the group (the last ntiles % 8 tiles form a smaller group).  Wave-uniform.
-__device__ __forceinline__ void ws_decode(unsigned b, unsigned ntiles, unsigned nc, int& tile, int& cby) {
+__host__ __device__ __forceinline__ void ws_decode(unsigned b, unsigned ntiles, unsigned nc, int& tile, int& cby) {
   if (nc == 1) {
     tile = (int)b;
     cby = 0;
@@ -1000,17 +1000,24 @@ __global__ __launch_bounds__(256, 2) void conv_ws_h2_kernel(const ConvParams p) 
 template <int KS>
 __global__ __launch_bounds__(256, 2) void conv_ws_multi(const ConvMulti m) {
   const unsigned b = blockIdx.x;
-  int sg = 0;
-#pragma unroll
-  for (int k = 1; k < kMultiSegs; ++k) sg += b >= m.seg_start[k];
+  int j, tile, cby;
   // (readfirstlane: the dynamically indexed kernel-argument reads are uniform, the compiler does not see it and
   // would wrap every weight load of the body in a waterfall loop)
-  const int j = __builtin_amdgcn_readfirstlane(m.seg_mem[sg]);
-  const unsigned r = __builtin_amdgcn_readfirstlane(b - m.seg_start[sg] + m.seg_first[sg]);
-  int tile, cby;
-  ws_decode(r, m.tiles[j], m.ncby[j], tile, cby);
-  tile = __builtin_amdgcn_readfirstlane(tile);
-  cby = __builtin_amdgcn_readfirstlane(cby);
+  if (m.tab_n) {
+    const unsigned e = __builtin_amdgcn_readfirstlane(m.tab[b >> 3]);
+    j = (int)(e & 3u);
+    cby = (int)((e >> 2) & 63u);
+    tile = (int)((e >> 8) + (b & 7u));
+  } else {
+    int sg = 0;
+#pragma unroll
+    for (int k = 1; k < kMultiSegs; ++k) sg += b >= m.seg_start[k];
+    j = __builtin_amdgcn_readfirstlane(m.seg_mem[sg]);
+    const unsigned r = __builtin_amdgcn_readfirstlane(b - m.seg_start[sg] + m.seg_first[sg]);
+    ws_decode(r, m.tiles[j], m.ncby[j], tile, cby);
+    tile = __builtin_amdgcn_readfirstlane(tile);
+    cby = __builtin_amdgcn_readfirstlane(cby);
+  }
   switch (m.code[j]) {
     case 1: conv_ws_body<KS, 1, 6, 1, false>(m.p[j], tile, (int)cby); break;
     case 2: conv_ws_body<KS, 1, 6, 2, false>(m.p[j], tile, (int)cby); break;
@@ -2340,6 +2347,22 @@ static void ws_order(ConvMulti* m, int n) {
     m->seg_first[s] = 0;
     m->seg_mem[s] = 0;
   }
+  // per-8 lookup table of the same order (see ConvMulti::tab)
+  m->tab_n = 0;
+  bool ok = total % 8 == 0 && total / 8 <= (unsigned)kMultiTab && getenv("UDP_POSE_WS_NOTAB") == nullptr;
+  for (int j = 0; j < n && ok; ++j) ok = m->tiles[j] % 8 == 0 && m->ncby[j] <= 64 && m->tiles[j] < (1u << 24);
+  for (int s = 0; s < ns && ok; ++s) ok = m->seg_start[s] % 8 == 0 && m->seg_first[s] % 8 == 0;
+  if (!ok) return;
+  for (int s = 0; s < ns; ++s) {
+    const unsigned end = s + 1 < ns ? m->seg_start[s + 1] : total;
+    const int j = m->seg_mem[s];
+    for (unsigned b = m->seg_start[s]; b < end; b += 8) {
+      int tile, cby;
+      ws_decode(b - m->seg_start[s] + m->seg_first[s], m->tiles[j], m->ncby[j], tile, cby);
+      m->tab[b >> 3] = (unsigned)j | ((unsigned)cby << 2) | ((unsigned)tile << 8);
+    }
+  }
+  m->tab_n = total / 8;
 }
 
 // Kernel + attribute for a merged launch of `n` groupable convs; fills the kernel argument.
