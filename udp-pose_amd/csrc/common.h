@@ -77,7 +77,7 @@ struct ConvMulti {
   unsigned seg_first[kMultiSegs];
   int seg_mem[kMultiSegs];
   // the same order resolved per run of 8 workgroups, when every boundary is a multiple of 8: tab[b >> 3] =
-  // member | cout block << 2 | first tile << 8, workgroup b takes tile (tab >> 8) + (b & 7).  ONE scalar load whose
+  // member | log2(CP) << 2 | cout block << 4 | first tile << 10, workgroup b takes tile (tab >> 10) + (b & 7).  ONE scalar load whose
   // address only needs blockIdx, instead of the table search + three dependent loads (1.6 us of every workgroup's
   // 15-60 us, tools/stamp_multi.py).  tab_n == 0: search the segment table.
   unsigned tab_n;

@@ -1003,11 +1003,14 @@ __global__ __launch_bounds__(256, 2) void conv_ws_multi(const ConvMulti m) {
   int j, tile, cby;
   // (readfirstlane: the dynamically indexed kernel-argument reads are uniform, the compiler does not see it and
   // would wrap every weight load of the body in a waterfall loop)
+  int code;
+  // the table entry is fetched together with tab_n (its address only needs blockIdx; entry 0 when out of range)
+  const unsigned e = __builtin_amdgcn_readfirstlane(m.tab[(b >> 3) < (unsigned)kMultiTab ? (b >> 3) : 0u]);
   if (m.tab_n) {
-    const unsigned e = __builtin_amdgcn_readfirstlane(m.tab[b >> 3]);
     j = (int)(e & 3u);
-    cby = (int)((e >> 2) & 63u);
-    tile = (int)((e >> 8) + (b & 7u));
+    code = 1 << ((e >> 2) & 3u);
+    cby = (int)((e >> 4) & 63u);
+    tile = (int)((e >> 10) + (b & 7u));
   } else {
     int sg = 0;
 #pragma unroll
@@ -1017,8 +1020,9 @@ __global__ __launch_bounds__(256, 2) void conv_ws_multi(const ConvMulti m) {
     ws_decode(r, m.tiles[j], m.ncby[j], tile, cby);
     tile = __builtin_amdgcn_readfirstlane(tile);
     cby = __builtin_amdgcn_readfirstlane(cby);
+    code = m.code[j];
   }
-  switch (m.code[j]) {
+  switch (code) {
     case 1: conv_ws_body<KS, 1, 6, 1, false>(m.p[j], tile, (int)cby); break;
     case 2: conv_ws_body<KS, 1, 6, 2, false>(m.p[j], tile, (int)cby); break;
     default: conv_ws_body<KS, 1, 6, 4, false>(m.p[j], tile, (int)cby); break;
@@ -2350,7 +2354,7 @@ static void ws_order(ConvMulti* m, int n) {
   // per-8 lookup table of the same order (see ConvMulti::tab)
   m->tab_n = 0;
   bool ok = total % 8 == 0 && total / 8 <= (unsigned)kMultiTab && getenv("UDP_POSE_WS_NOTAB") == nullptr;
-  for (int j = 0; j < n && ok; ++j) ok = m->tiles[j] % 8 == 0 && m->ncby[j] <= 64 && m->tiles[j] < (1u << 24);
+  for (int j = 0; j < n && ok; ++j) ok = m->tiles[j] % 8 == 0 && m->ncby[j] <= 64 && m->tiles[j] < (1u << 22) && (m->code[j] == 1 || m->code[j] == 2 || m->code[j] == 4);
   for (int s = 0; s < ns && ok; ++s) ok = m->seg_start[s] % 8 == 0 && m->seg_first[s] % 8 == 0;
   if (!ok) return;
   for (int s = 0; s < ns; ++s) {
@@ -2359,7 +2363,8 @@ static void ws_order(ConvMulti* m, int n) {
     for (unsigned b = m->seg_start[s]; b < end; b += 8) {
       int tile, cby;
       ws_decode(b - m->seg_start[s] + m->seg_first[s], m->tiles[j], m->ncby[j], tile, cby);
-      m->tab[b >> 3] = (unsigned)j | ((unsigned)cby << 2) | ((unsigned)tile << 8);
+      const unsigned cl = m->code[j] == 1 ? 0u : m->code[j] == 2 ? 1u : 2u;      // log2 of the member's CP
+      m->tab[b >> 3] = (unsigned)j | (cl << 2) | ((unsigned)cby << 4) | ((unsigned)tile << 10);
     }
   }
   m->tab_n = total / 8;
