@@ -293,6 +293,18 @@ size_t udp_conv2d_wgrad_workspace_bytes(int cout, int cin, int ks);
 int udp_conv2d_wgrad(const void* x, const void* dy, int n, int hin, int win, int cin_k, int hout,
                      int wout, int cout_k, int ks, int stride, int cout, int cin, int dtype, float* dw,
                      int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+/* The weight gradients of up to 4 convs (the same-depth convs of the HRNet branches): the partial-sum kernels run
+ * one per member, the fixed-order reduces of all members as ONE launch; results are those of udp_conv2d_wgrad per
+ * member, bit for bit.  Every member needs its own workspace. */
+typedef struct udp_wgrad_item {
+  const void* x;
+  const void* dy;
+  float* dw;
+  void* workspace;
+  size_t workspace_bytes;
+  int32_t n, hin, win, cin_k, hout, wout, cout_k, ks, stride, cout, cin, accumulate;
+} udp_wgrad_item;
+int udp_conv2d_wgrad_group(const udp_wgrad_item* items, int n_items, int dtype, void* stream);
 /* Up to 4 independent plain convs (same dtype and batch n) in as few launches as possible -- the same-depth convs
  * of the HRNet branches in the training step (pose_hrnet.py:253-256): members whose tile fits the merged kernel run
  * as ONE launch, the rest on their own; per-member results are those of udp_conv2d_fused / udp_conv2d_fused_bn.

@@ -458,6 +458,41 @@ def test_grouped_conv_launch_equals_single_launches(dtype):
         _lib.check(L.udp_conv2d_fused_group(items, 4, dt, n, _stream()))
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_grouped_weight_gradients_equal_single_calls(dtype):
+    """udp_conv2d_wgrad_group (partial sums one launch per member, the fixed-order reduces of all members as ONE
+    launch) against udp_conv2d_wgrad per member on the four W32 branch shapes: bit for bit; a shared workspace
+    is refused."""
+    L = _lib.lib()
+    dt, tdt = _lib.DTYPES[dtype], (torch.bfloat16 if dtype == "bf16" else torch.float32)
+    g = torch.Generator().manual_seed(31)
+    n = 4
+    shapes = [(256, 8, 6), (128, 16, 12), (64, 32, 24), (32, 64, 48)]
+    items = (_lib.WgradItem * 4)()
+    keep, singles, groups = [], [], []
+    for it, (c, h, w) in zip(items, shapes):
+        x = torch.randn(n, h, w, c, generator=g).to(tdt).cuda()
+        dy = torch.randn(n, h, w, c, generator=g).to(tdt).cuda()
+        wsb = L.udp_conv2d_wgrad_workspace_bytes(c, c, 3)
+        ws0, ws1 = (torch.empty(wsb, dtype=torch.uint8, device="cuda") for _ in range(2))
+        d0, d1 = torch.zeros(c, c, 3, 3, device="cuda"), torch.zeros(c, c, 3, 3, device="cuda")
+        _lib.check(L.udp_conv2d_wgrad(x.data_ptr(), dy.data_ptr(), n, h, w, c, h, w, c, 3, 1, c, c, dt, d0.data_ptr(), 0,
+                                      ws0.data_ptr(), wsb, _stream()))
+        it.x, it.dy, it.dw, it.workspace, it.workspace_bytes = x.data_ptr(), dy.data_ptr(), d1.data_ptr(), ws1.data_ptr(), wsb
+        it.n, it.hin, it.win, it.cin_k, it.hout, it.wout, it.cout_k = n, h, w, c, h, w, c
+        it.ks, it.stride, it.cout, it.cin, it.accumulate = 3, 1, c, c, 0
+        keep += [x, dy, ws0, ws1]
+        singles.append(d0)
+        groups.append(d1)
+    _lib.check(L.udp_conv2d_wgrad_group(items, 4, dt, _stream()))
+    torch.cuda.synchronize()
+    for a, b in zip(singles, groups):
+        assert float(a.abs().max()) > 0 and torch.equal(a, b)
+    items[1].workspace = items[0].workspace
+    with pytest.raises(_lib.UdpPoseError):
+        _lib.check(L.udp_conv2d_wgrad_group(items, 4, dt, _stream()))
+
+
 def test_w32_train_step_at_config3_size(golden_dir):
     """BASELINE config 3 at its own per-GPU size: pose_hrnet_w32 256x192, JointsMSELoss, 32 images.  One
     train_step (fp32) against the CPU oracle's train-mode forward + criterion + autograd (oracle/train.py =

@@ -27,6 +27,13 @@ class BnItem(C.Structure):
         ("m", C.c_int64), ("c", C.c_int32), ("rows", C.c_int32), ("relu", C.c_int32), ("reserved", C.c_int32)]
 
 
+class WgradItem(C.Structure):
+    """struct udp_wgrad_item (include/udp_pose_hip.h): one member of udp_conv2d_wgrad_group."""
+    _fields_ = [("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_size_t)] + [(k, C.c_int32) for k in (
+                    "n", "hin", "win", "cin_k", "hout", "wout", "cout_k", "ks", "stride", "cout", "cin", "accumulate")]
+
+
 class ConvItem(C.Structure):
     """struct udp_conv_item (include/udp_pose_hip.h): one member of udp_conv2d_fused_group."""
     _fields_ = [("op", C.c_void_p), ("inp", C.c_void_p), ("weights", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p),
@@ -111,6 +118,7 @@ _SIGS = {
     "udp_bn_train_fwd_from_sums": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P, _P,
                                              C.c_int, _P, C.c_int, _P, C.c_int, _P]),
     "udp_bn_train_bwd": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
+    "udp_conv2d_wgrad_group": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "udp_conv2d_fused_group": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     "udp_bn_train_fwd_multi": (C.c_int, [_P, C.c_int, C.c_float, C.c_float, C.c_int, _P]),
     "udp_bn_train_bwd_multi": (C.c_int, [_P, C.c_int, C.c_int, _P]),

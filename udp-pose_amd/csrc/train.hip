@@ -326,12 +326,12 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradParams p) {
 
 // dw[co][ci][tap] (+)= sum_s part[s][tap][co][ci].  Block = 16 element quads x 16 split lanes
 // (fixed summation order: deterministic).
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int splits, int taps, int cout,
-                                                           int cin, int accumulate, float* __restrict__ dw) {
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part, int splits, int taps, int cout,
+                                                  int cin, int accumulate, float* __restrict__ dw, unsigned bx) {
   __shared__ f32x4 red[16][17];
   const long per = (long)taps * cout * cin;          // multiple of 4? not necessarily: tail handled scalar
   const int q = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const long i4 = ((long)blockIdx.x * 16 + q) * 4;
+  const long i4 = ((long)bx * 16 + q) * 4;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (i4 + 3 < per && (per & 3) == 0) {
     for (int k = sl; k < splits; k += 16) s += *reinterpret_cast<const f32x4*>(part + k * per + i4);
@@ -352,6 +352,22 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       *d = accumulate ? *d + s[e] : s[e];
     }
   }
+}
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int splits, int taps, int cout,
+                                                           int cin, int accumulate, float* __restrict__ dw) {
+  wgrad_reduce_body(part, splits, taps, cout, cin, accumulate, dw, blockIdx.x);
+}
+// the reduces of up to 4 weight gradients (the same-depth convs of the HRNet branches) in one launch
+struct WgradReduceMulti {
+  const float* part[4];
+  float* dw[4];
+  int splits[4], taps[4], cout[4], cin[4], accumulate[4];
+  unsigned start[5];
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_multi(const WgradReduceMulti a) {
+  const unsigned b = blockIdx.x;
+  const int j = __builtin_amdgcn_readfirstlane((b >= a.start[1]) + (b >= a.start[2]) + (b >= a.start[3]));
+  wgrad_reduce_body(a.part[j], a.splits[j], a.taps[j], a.cout[j], a.cin[j], a.accumulate[j], a.dw[j], b - a.start[j]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -808,9 +824,9 @@ extern "C" size_t udp_conv2d_wgrad_workspace_bytes(int cout, int cin, int ks) {
   return want;
 }
 
-extern "C" int udp_conv2d_wgrad(const void* x, const void* dy, int n, int hin, int win, int cin_k, int hout, int wout,
-                                int cout_k, int ks, int stride, int cout, int cin, int dtype, float* dw, int accumulate,
-                                void* workspace, size_t workspace_bytes, void* stream) {
+static int wgrad_partials(const void* x, const void* dy, int n, int hin, int win, int cin_k, int hout, int wout,
+                          int cout_k, int ks, int stride, int cout, int cin, int dtype, float* dw,
+                          void* workspace, size_t workspace_bytes, void* stream, int* splits_out) {
   if (!x || !dy || !dw || !workspace) return fail(UDP_ERR_ARG, "udp_conv2d_wgrad: null pointer");
   if (check_dtype(dtype, "udp_conv2d_wgrad")) return UDP_ERR_ARG;
   if (n <= 0 || (ks != 1 && ks != 3) || (stride != 1 && stride != 2) || cout <= 0 || cin <= 0 || cout > cout_k ||
@@ -879,9 +895,50 @@ extern "C" int udp_conv2d_wgrad(const void* x, const void* dy, int n, int hin, i
   if (lds > 64 * 1024) UDP_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   void* args[] = {&p};
   UDP_HIP_CHECK(hipLaunchKernel(fn, grid, dim3(256), args, lds, s));
+  *splits_out = splits;
+  return UDP_OK;
+}
+
+extern "C" int udp_conv2d_wgrad(const void* x, const void* dy, int n, int hin, int win, int cin_k, int hout, int wout,
+                                int cout_k, int ks, int stride, int cout, int cin, int dtype, float* dw, int accumulate,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  int splits = 0;
+  const int rc = wgrad_partials(x, dy, n, hin, win, cin_k, hout, wout, cout_k, ks, stride, cout, cin, dtype, dw, workspace,
+                                workspace_bytes, stream, &splits);
+  if (rc) return rc;
   const long total = (long)ks * ks * cout * cin;
-  wgrad_reduce_kernel<<<nblocks(total, 64), 256, 0, s>>>(p.part, splits, ks * ks, cout, cin, accumulate, dw);
+  wgrad_reduce_kernel<<<nblocks(total, 64), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(
+      reinterpret_cast<const float*>(workspace), splits, ks * ks, cout, cin, accumulate, dw);
   return launched("udp_conv2d_wgrad");
+}
+
+extern "C" int udp_conv2d_wgrad_group(const udp_wgrad_item* items, int n_items, int dtype, void* stream) {
+  if (!items || n_items < 1 || n_items > 4) return fail(UDP_ERR_ARG, "udp_conv2d_wgrad_group: %d members (1..4)", n_items);
+  WgradReduceMulti a;
+  memset(&a, 0, sizeof(a));
+  unsigned tot = 0;
+  for (int j = 0; j < n_items; ++j) {
+    const udp_wgrad_item& q = items[j];
+    for (int k = 0; k < j; ++k)
+      if (items[k].workspace == q.workspace) return fail(UDP_ERR_ARG, "udp_conv2d_wgrad_group: members %d and %d share a workspace", k, j);
+    int splits = 0;
+    const int rc = wgrad_partials(q.x, q.dy, q.n, q.hin, q.win, q.cin_k, q.hout, q.wout, q.cout_k, q.ks, q.stride, q.cout, q.cin,
+                                  dtype, q.dw, q.workspace, q.workspace_bytes, stream, &splits);
+    if (rc) return rc;
+    a.part[j] = reinterpret_cast<const float*>(q.workspace);
+    a.dw[j] = q.dw;
+    a.splits[j] = splits;
+    a.taps[j] = q.ks * q.ks;
+    a.cout[j] = q.cout;
+    a.cin[j] = q.cin;
+    a.accumulate[j] = q.accumulate;
+    a.start[j] = tot;
+    tot += nblocks((long)q.ks * q.ks * q.cout * q.cin, 64);
+  }
+  for (int j = n_items; j < 5; ++j) a.start[j] = j < 4 ? 0xFFFFFFFFu : tot;
+  a.start[4] = tot;
+  wgrad_reduce_multi<<<tot, 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(a);
+  return launched("udp_conv2d_wgrad_group");
 }
 
 extern "C" size_t udp_bn_workspace_doubles(int c) { return c > 0 ? (size_t)(kBnMaxBlocks + 1) * 2 * c : 0; }

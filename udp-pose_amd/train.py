@@ -110,6 +110,8 @@ class HRNetTrainer:
             self._convs[k[:-len(".weight")]] = (cout, cin, ks, fwd, dg)
             ws_bytes = max(ws_bytes, _lib.lib().udp_conv2d_wgrad_workspace_bytes(cout, cin, ks))
         self._wgrad_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
+        # one more per branch slot: the weight gradients of a lock-step level keep their partials until the common reduce
+        self._wgrad_wss = [self._wgrad_ws] + [torch.empty(ws_bytes, dtype=torch.uint8, device=self.device) for _ in range(3)]
         descs = (_lib.PackDesc * len(self._convs))()
         for i, (name, (cout, cin, ks, fwd, dg)) in enumerate(self._convs.items()):
             descs[i].w, descs[i].w_fwd = self._p(name + ".weight"), fwd.data_ptr()
@@ -379,14 +381,20 @@ class HRNetTrainer:
 
         def backward():
             gi = (_lib.ConvItem * nb)()
+            wi = (_lib.WgradItem * nb)()
             dops, k = [], 0
-            for b in order:
+            for slot, b in enumerate(order):
                 x, y, (cout, cin, ks, wf, wd) = xs[b], ys[b], metas[b]
                 if y.grad is None:
                     y.grad = torch.zeros_like(y.buf)
-                _lib.check(L.udp_conv2d_wgrad(x.buf.data_ptr(), y.grad.data_ptr(), x.n, x.h, x.w, x.ck, x.h, x.w, y.ck, ks,
-                                              1, cout, cin, self._dt, self._g(names[b] + ".weight"), 0,
-                                              self._wgrad_ws.data_ptr(), self._wgrad_ws.numel(), self._stream()))
+                w = wi[slot]                           # partial sums one launch per member, their reduces one launch
+                w.x, w.dy, w.dw = x.buf.data_ptr(), y.grad.data_ptr(), self._g(names[b] + ".weight")
+                w.workspace, w.workspace_bytes = self._wgrad_wss[slot].data_ptr(), self._wgrad_wss[slot].numel()
+                w.n, w.hin, w.win, w.cin_k, w.hout, w.wout, w.cout_k = x.n, x.h, x.w, x.ck, x.h, x.w, y.ck
+                w.ks, w.stride, w.cout, w.cin, w.accumulate = ks, 1, cout, cin, 0
+            _lib.check(L.udp_conv2d_wgrad_group(wi, nb, self._dt, self._stream()))
+            for b in order:
+                x, y, (cout, cin, ks, wf, wd) = xs[b], ys[b], metas[b]
                 if not x.needs_grad:
                     continue
                 res = x.grad
