@@ -185,7 +185,8 @@ def test_bench_gpus_n_launches_its_own_ranks():
     import torch
     if not torch.cuda.is_available():
         assert r.returncode != 0
-        assert (r.stdout + r.stderr).count("bench.py needs a GPU") == 2
+        # both ranks print it unless the launcher, seeing the first rank fail, stops the second before it gets there
+        assert 1 <= (r.stdout + r.stderr).count("bench.py needs a GPU") <= 2
 
 
 def test_f16x2_host_encoding_and_fragment_major_weights():
