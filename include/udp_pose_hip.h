@@ -304,6 +304,13 @@ typedef struct udp_wgrad_item {
   size_t workspace_bytes;
   int32_t n, hin, win, cin_k, hout, wout, cout_k, ks, stride, cout, cin, accumulate;
 } udp_wgrad_item;
+/* Diagnostic, host only (no GPU): the dispatch order of a merged weight-stationary launch whose member j has
+ * tiles[j] pixel tiles x ncby[j] cout blocks and kernel variant code[j] (1, 2 or 4): for every flat workgroup
+ * b < total the member, tile and cout block it computes, resolved as the kernel resolves them.  Returns total
+ * (<= cap), -1 on error; *used_table = 1 when the one-load lookup table applies.  Tests check that every
+ * (member, tile, cout block) is computed exactly once. */
+int udp_debug_multi_order(const unsigned* tiles, const unsigned* ncby, const int* code, int n, unsigned cap,
+                          unsigned* out_member, unsigned* out_tile, unsigned* out_cby, int* used_table);
 int udp_conv2d_wgrad_group(const udp_wgrad_item* items, int n_items, int dtype, void* stream);
 /* Up to 4 independent plain convs (same dtype and batch n) in as few launches as possible -- the same-depth convs
  * of the HRNet branches in the training step (pose_hrnet.py:253-256): members whose tile fits the merged kernel run

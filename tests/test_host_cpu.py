@@ -173,6 +173,40 @@ def test_launch_groups_are_independent():
             assert not (reads & (set(outs) - {o.out_buf})), (g, i)
 
 
+def test_merged_launch_dispatch_order_is_a_permutation():
+    """ws_order + the per-8 lookup table (csrc/conv.hip): whatever the member sizes -- the W32 / W48 / RSN groups at
+    several batch sizes, counts that are not multiples of 8 (segment-search fallback), one cout block or many --
+    every (member, tile, cout block) is computed by exactly one workgroup, the deepest member's workgroups all
+    sit in the first chip-wide round, and the launch ends on the shallowest member."""
+    lib = _lib.lib()
+    rng = np.random.default_rng(7)
+    cases = [([64, 256, 512, 1024], [2, 1, 1, 1], [4, 4, 2, 1]), ([256, 512, 1024], [1, 1, 1], [4, 2, 1]),
+             ([512, 1024], [1, 1], [2, 1]), ([16, 64, 128, 256], [2, 1, 1, 1], [4, 4, 2, 1]),
+             ([3, 10, 19, 38], [2, 1, 1, 1], [4, 4, 2, 1]), ([8, 8], [1, 3], [4, 1]), ([1, 1, 1, 1], [1, 1, 1, 1], [1, 1, 1, 1])]
+    for _ in range(40):
+        n = int(rng.integers(2, 5))
+        mult = 8 if rng.random() < 0.6 else 1
+        cases.append(([int(rng.integers(1, 200)) * mult for _ in range(n)], [int(rng.integers(1, 5)) for _ in range(n)],
+                      [int(rng.choice([1, 2, 4])) for _ in range(n)]))
+    seen_table = seen_search = False
+    for tiles, ncby, code in cases:
+        n = len(tiles)
+        total = sum(t * c for t, c in zip(tiles, ncby))
+        om, ot, oc = (np.zeros(total, np.uint32) for _ in range(3))
+        used = C.c_int(0)
+        got = lib.udp_debug_multi_order((C.c_uint * n)(*tiles), (C.c_uint * n)(*ncby), (C.c_int * n)(*code), n, total,
+                                        om.ctypes.data, ot.ctypes.data, oc.ctypes.data, C.byref(used))
+        assert got == total, (tiles, ncby)
+        seen_table |= bool(used.value)
+        seen_search |= not used.value
+        want = sorted((j, t, c) for j in range(n) for t in range(tiles[j]) for c in range(ncby[j]))
+        assert sorted(zip(om.tolist(), ot.tolist(), oc.tolist())) == want, (tiles, ncby, code)
+        if total > 512 and tiles[0] * ncby[0] <= 256 and tiles[-1] * ncby[-1] >= total // 3 and used.value:
+            assert np.all(np.nonzero(om == 0)[0] < 512 + 64), (tiles, ncby)      # deepest member: first round
+            assert om[-1] == n - 1                                             # the launch ends on short workgroups
+    assert seen_table and seen_search
+
+
 def test_bench_gpus_n_launches_its_own_ranks():
     """`bench.py --gpus 2` from a plain shell (no torch.distributed environment) starts two ranks of itself
     before touching the GPU; in this GPU-less container both stop at the explicit "needs a GPU" exit and the

@@ -118,6 +118,7 @@ _SIGS = {
     "udp_bn_train_fwd_from_sums": (C.c_int, [_P, C.c_int64, C.c_int, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P, _P,
                                              C.c_int, _P, C.c_int, _P, C.c_int, _P]),
     "udp_bn_train_bwd": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
+    "udp_debug_multi_order": (C.c_int, [_P, _P, _P, C.c_int, C.c_uint, _P, _P, _P, _P]),
     "udp_conv2d_wgrad_group": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "udp_conv2d_fused_group": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P]),
     "udp_bn_train_fwd_multi": (C.c_int, [_P, C.c_int, C.c_float, C.c_float, C.c_int, _P]),

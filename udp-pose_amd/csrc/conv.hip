@@ -2370,6 +2370,49 @@ static void ws_order(ConvMulti* m, int n) {
   m->tab_n = total / 8;
 }
 
+// Diagnostic (tests/test_host_cpu.py, no GPU needed): the dispatch tables ws_order builds for members of
+// tiles[j] x ncby[j] workgroups, resolved for every flat block exactly as conv_ws_multi resolves them (table entry
+// when there is one, segment search otherwise).  out_*[b] for b < total; returns total, or -1.
+extern "C" int udp_debug_multi_order(const unsigned* tiles, const unsigned* ncby, const int* code, int n, unsigned cap,
+                                     unsigned* out_member, unsigned* out_tile, unsigned* out_cby, int* used_table) {
+  if (!tiles || !ncby || !code || n < 1 || n > 4 || !out_member || !out_tile || !out_cby) return -1;
+  static ConvMulti m;
+  memset(&m, 0, sizeof(m));
+  unsigned total = 0;
+  for (int j = 0; j < n; ++j) {
+    m.start[j] = total;
+    m.tiles[j] = tiles[j];
+    m.ncby[j] = ncby[j];
+    m.code[j] = code[j];
+    total += tiles[j] * ncby[j];
+  }
+  for (int j = n; j < 5; ++j) m.start[j] = j < 4 ? 0xFFFFFFFFu : total;
+  m.start[4] = total;
+  for (int j = n; j < 4; ++j) m.tiles[j] = m.ncby[j] = 1;
+  if (total > cap) return -1;
+  ws_order(&m, n);
+  if (used_table) *used_table = m.tab_n != 0;
+  for (unsigned b = 0; b < total; ++b) {
+    int j, tile, cby;
+    if (m.tab_n) {
+      const unsigned e = m.tab[b >> 3];
+      j = (int)(e & 3u);
+      if ((1 << ((e >> 2) & 3u)) != m.code[j]) return -1;
+      cby = (int)((e >> 4) & 63u);
+      tile = (int)((e >> 10) + (b & 7u));
+    } else {
+      int sg = 0;
+      for (int k = 1; k < kMultiSegs; ++k) sg += b >= m.seg_start[k];
+      j = m.seg_mem[sg];
+      ws_decode(b - m.seg_start[sg] + m.seg_first[sg], m.tiles[j], m.ncby[j], tile, cby);
+    }
+    out_member[b] = (unsigned)j;
+    out_tile[b] = (unsigned)tile;
+    out_cby[b] = (unsigned)cby;
+  }
+  return (int)total;
+}
+
 // Kernel + attribute for a merged launch of `n` groupable convs; fills the kernel argument.
 int describe_multi(const Launch* members, int n, ConvMulti* m, Launch* out) {
   static bool attr_set = false;
