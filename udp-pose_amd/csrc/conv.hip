@@ -2298,76 +2298,90 @@ int describe_conv_grouped(ConvParams p, int dtype, int ks, int stride, Launch* o
 // Chunks are multiples of 8 workgroups (one per XCD -- workgroup i runs on XCD i % 8, an uneven pattern would
 // leave some XCDs with all the long workgroups).  UDP_POSE_WS_ORDER=lpt keeps the plain member-after-member order.
 static void ws_order(ConvMulti* m, int n) {
-  unsigned lo[4], hi[4];
+  struct Seg {
+    unsigned start, first, cnt;
+    int mem;
+  };
+  unsigned cnt_of[4];
   unsigned total = 0;
   for (int j = 0; j < n; ++j) {
-    lo[j] = 0;
-    hi[j] = (j + 1 < n ? m->start[j + 1] : m->start[4]) - m->start[j];
-    total += hi[j];
+    cnt_of[j] = (j + 1 < n ? m->start[j + 1] : m->start[4]) - m->start[j];
+    total += cnt_of[j];
   }
-  int ns = 0;
-  unsigned at = 0;
-  auto take = [&](int j, unsigned cnt) {
-    if (cnt > hi[j] - lo[j]) cnt = hi[j] - lo[j];
-    if (!cnt) return;
-    if (!(ns && m->seg_mem[ns - 1] == j && m->seg_first[ns - 1] + (at - m->seg_start[ns - 1]) == lo[j])) {
-      m->seg_start[ns] = at;
-      m->seg_first[ns] = lo[j];
-      m->seg_mem[ns] = j;
-      ++ns;
-    }
-    lo[j] += cnt;
-    at += cnt;
-  };
   const char* mode = getenv("UDP_POSE_WS_ORDER");
-  if (!(mode && strcmp(mode, "lpt") == 0)) {
-    // chunk size: 32 workgroups, more when the table would not hold the launch (two entries stay free per member)
-    unsigned g = 32;
-    while ((total + g - 1) / g > (unsigned)(kMultiSegs - 2 * n)) g += 8;
-    const unsigned nb = hi[n - 1];
-    const unsigned na = total - nb;
-    unsigned ta = 0, tb = 0;                 // taken from A / B so far
-    // list A runs 25 % ahead of its share, so the deep members are exhausted first and the launch ends on the short
-    // workgroups of B alone (tail = one 15 us workgroup instead of a 20-25 us one): +2 % (UDP_POSE_WS_BIAS, percent)
-    const unsigned bias = getenv("UDP_POSE_WS_BIAS") ? (unsigned)atoi(getenv("UDP_POSE_WS_BIAS")) : 125u;
-    while (ta < na && tb < nb && ns < kMultiSegs - n) {
-      // the list that is behind its share goes next (ties: A, so that the deepest workgroups lead the grid)
-      if ((unsigned long long)ta * nb * 100ull <= (unsigned long long)tb * na * bias) {
-        int j = 0;
-        while (lo[j] == hi[j]) ++j;
-        const unsigned c = hi[j] - lo[j] < g ? hi[j] - lo[j] : g;
-        take(j, c);
-        ta += c;
-      } else {
-        const unsigned c = nb - tb < g ? nb - tb : g;
-        take(n - 1, c);
-        tb += c;
+  const bool lpt = mode && strcmp(mode, "lpt") == 0;
+  // list A runs 25 % ahead of its share, so the deep members are exhausted first and the launch ends on the short
+  // workgroups of B alone (tail = one 15 us workgroup instead of a 20-25 us one): +2 % (UDP_POSE_WS_BIAS, percent)
+  const unsigned bias = getenv("UDP_POSE_WS_BIAS") ? (unsigned)atoi(getenv("UDP_POSE_WS_BIAS")) : 125u;
+  auto build = [&](unsigned g) {
+    std::vector<Seg> segs;
+    unsigned lo[4] = {0, 0, 0, 0};
+    unsigned at = 0;
+    auto take = [&](int j, unsigned cnt) {
+      if (cnt > cnt_of[j] - lo[j]) cnt = cnt_of[j] - lo[j];
+      if (!cnt) return;
+      if (!segs.empty() && segs.back().mem == j && segs.back().first + segs.back().cnt == lo[j])
+        segs.back().cnt += cnt;
+      else
+        segs.push_back({at, lo[j], cnt, j});
+      lo[j] += cnt;
+      at += cnt;
+    };
+    if (!lpt) {
+      const unsigned nb = cnt_of[n - 1];
+      const unsigned na = total - nb;
+      unsigned ta = 0, tb = 0;                 // taken from A / B so far
+      while (ta < na && tb < nb) {
+        // the list that is behind its share goes next (ties: A, so that the deepest workgroups lead the grid)
+        if ((unsigned long long)ta * nb * 100ull <= (unsigned long long)tb * na * bias) {
+          int j = 0;
+          while (lo[j] == cnt_of[j]) ++j;
+          const unsigned c = cnt_of[j] - lo[j] < g ? cnt_of[j] - lo[j] : g;
+          take(j, c);
+          ta += c;
+        } else {
+          const unsigned c = nb - tb < g ? nb - tb : g;
+          take(n - 1, c);
+          tb += c;
+        }
       }
     }
-  }
-  for (int j = 0; j < n; ++j) take(j, hi[j] - lo[j]);
-  for (int s = ns; s < kMultiSegs; ++s) {
-    m->seg_start[s] = 0xFFFFFFFFu;
-    m->seg_first[s] = 0;
-    m->seg_mem[s] = 0;
-  }
-  // per-8 lookup table of the same order (see ConvMulti::tab)
+    for (int j = 0; j < n; ++j) take(j, cnt_of[j] - lo[j]);
+    return segs;
+  };
+  // chunk size: 32 workgroups (UDP_POSE_WS_G); the per-8 lookup table (ConvMulti::tab) takes any number of chunks,
+  // the segment table searched without it holds kMultiSegs
+  unsigned g = getenv("UDP_POSE_WS_G") ? (unsigned)atoi(getenv("UDP_POSE_WS_G")) : 32u;
+  if (g < 8 || g % 8) g = 32;
+  std::vector<Seg> segs = build(g);
   m->tab_n = 0;
   bool ok = total % 8 == 0 && total / 8 <= (unsigned)kMultiTab && getenv("UDP_POSE_WS_NOTAB") == nullptr;
-  for (int j = 0; j < n && ok; ++j) ok = m->tiles[j] % 8 == 0 && m->ncby[j] <= 64 && m->tiles[j] < (1u << 22) && (m->code[j] == 1 || m->code[j] == 2 || m->code[j] == 4);
-  for (int s = 0; s < ns && ok; ++s) ok = m->seg_start[s] % 8 == 0 && m->seg_first[s] % 8 == 0;
-  if (!ok) return;
-  for (int s = 0; s < ns; ++s) {
-    const unsigned end = s + 1 < ns ? m->seg_start[s + 1] : total;
-    const int j = m->seg_mem[s];
-    for (unsigned b = m->seg_start[s]; b < end; b += 8) {
-      int tile, cby;
-      ws_decode(b - m->seg_start[s] + m->seg_first[s], m->tiles[j], m->ncby[j], tile, cby);
-      const unsigned cl = m->code[j] == 1 ? 0u : m->code[j] == 2 ? 1u : 2u;      // log2 of the member's CP
-      m->tab[b >> 3] = (unsigned)j | (cl << 2) | ((unsigned)cby << 4) | ((unsigned)tile << 10);
+  for (int j = 0; j < n && ok; ++j)
+    ok = m->tiles[j] % 8 == 0 && m->ncby[j] <= 64 && m->tiles[j] < (1u << 22) && (m->code[j] == 1 || m->code[j] == 2 || m->code[j] == 4);
+  for (size_t k = 0; k < segs.size() && ok; ++k) ok = segs[k].start % 8 == 0 && segs[k].first % 8 == 0;
+  if (ok) {
+    for (const Seg& sg : segs) {
+      const int j = sg.mem;
+      for (unsigned b = sg.start; b < sg.start + sg.cnt; b += 8) {
+        int tile, cby;
+        ws_decode(b - sg.start + sg.first, m->tiles[j], m->ncby[j], tile, cby);
+        const unsigned cl = m->code[j] == 1 ? 0u : m->code[j] == 2 ? 1u : 2u;      // log2 of the member's CP
+        m->tab[b >> 3] = (unsigned)j | (cl << 2) | ((unsigned)cby << 4) | ((unsigned)tile << 10);
+      }
     }
+    m->tab_n = total / 8;
   }
-  m->tab_n = total / 8;
+  // the searched table (read by the kernel only when there is no lookup table): coarser chunks until it fits
+  while (segs.size() > (size_t)kMultiSegs) {
+    g += 8;
+    segs = build(g);
+  }
+  for (int k = 0; k < kMultiSegs; ++k) {
+    const bool have = (size_t)k < segs.size();
+    m->seg_start[k] = have ? segs[k].start : 0xFFFFFFFFu;
+    m->seg_first[k] = have ? segs[k].first : 0;
+    m->seg_mem[k] = have ? segs[k].mem : 0;
+  }
 }
 
 // Diagnostic (tests/test_host_cpu.py, no GPU needed): the dispatch tables ws_order builds for members of
