@@ -148,7 +148,8 @@ def roofline(net, hp, steps, dtype):
     # profiles/r02_traffic_<dtype>.json together with the SHA-256 of the library it profiled): reported only
     # when that library is the one loaded now, null otherwise -- never a number from another build
     traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r02_traffic_%s.json" % dtype)
+    tfile = next((f for f in (os.path.join(ROOT, "profiles", "r%02d_traffic_%s.json" % (r, dtype)) for r in (3, 2))
+                  if os.path.exists(f)), os.path.join(ROOT, "profiles", "r03_traffic_%s.json" % dtype))
     tj = {}
     if os.path.exists(tfile) and hp.n == 64 and hp.h == 256:
         try:
@@ -292,6 +293,121 @@ def time_mode(dtype, args, device, rank, in_h, in_w, tt, barrier):
     return sd, net, hp, dt
 
 
+def golden_parity(model, dtype, device):
+    """Heat-maps of the timed mode on the crop the REFERENCE module was run on when tests/golden was made
+    (oracle/gen_golden.py): max abs error and arg-max agreement.  Data files only -- nothing of the reference is read."""
+    name = {"w48": "hrnet_w48_gaussian.npz", "rsn18": "rsn18_51.npz"}[model]
+    g = np.load(os.path.join(ROOT, "tests", "golden", name))
+    _, h, w, _ = MODELS_CFG[model]
+    seed = {"w48": 6, "rsn18": 8}[model]
+    _, net = build_net(dtype, target_type="offset" if model == "rsn18" else "gaussian", model=model)
+    x = torch.from_numpy(synth.synth_crops(1, h, w, seed=seed)).to(device)
+    got = net.to(device)(x).clone().cpu().numpy()
+    ref = g["out"]
+    ch = ref.shape[1]
+    hm_ch = slice(0, ch, 3) if model == "rsn18" else slice(None)        # offset head: arg-max on the heat-map channels
+    return {"fixture": "tests/golden/" + name + " (reference module output, 1 crop)",
+            "heatmap_max_abs_err": float(np.abs(got - ref).max()),
+            "argmax_equal_rate": float((got[:, hm_ch].reshape(-1, ref.shape[2] * ref.shape[3]).argmax(1) ==
+                                        ref[:, hm_ch].reshape(-1, ref.shape[2] * ref.shape[3]).argmax(1)).mean()),
+            "tolerance": 3e-3 if model == "rsn18" else 1e-3}
+
+
+def time_other_inference(model, args, device):
+    """BASELINE.json configs[3] / configs[4] in the parity-grade mode: same step definition as the headline."""
+    import copy
+    a = copy.copy(args)
+    a.model, a.batch = model, (32 if model == "w48" else 64)
+    _, h, w, _ = MODELS_CFG[model]
+    tt = "offset" if model == "rsn18" else "gaussian"
+    sd, net, hp, dt = time_mode("f16x2", a, device, 0, h, w, tt, torch.cuda.synchronize)
+    ms = dt / a.steps * 1e3
+    out = {"workload": "%s %dx%d f16x2 inference, batch=%d, flip-test on, %s decode" % (model, h, w, a.batch, "DARK" if tt == "gaussian" else "offset"),
+           "value": round(a.batch * a.steps / dt, 1), "unit": "images/s", "ms_per_step": round(ms, 4), "dtype": "f16x2"}
+    try:
+        r = roofline(net, hp, 3, "f16x2")
+        out["roofline"] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "launches_per_step", "avg_launch_us")}
+        flops_per_img = 2 * 2 * net.program(h, w).macs_per_image()
+        out["whole_step_tflops"] = round(flops_per_img * a.batch / (ms * 1e-3) / 1e12, 2)
+    except Exception as e:                                          # noqa: BLE001
+        out["roofline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    del hp, net
+    out["parity"] = golden_parity(model, "f16x2", device)
+    return out
+
+
+def time_train_step(dtype, args, device, sd):
+    """BASELINE.json configs[2] on one GPU (its per-GPU share: 32 images): train-mode forward + JointsMSELoss +
+    backward + Adam of pose_hrnet_w32 256x192, replayed as a hipGraph (function.train's path).  Parity: the step-0
+    loss of 8 of the images against the CPU oracle's train-mode forward + criterion (oracle/train.py)."""
+    from udp_pose_amd.train import HRNetTrainer
+    cfg = {"MODEL": {"EXTRA": synth.W32_EXTRA, "NUM_JOINTS": 17, "TARGET_TYPE": "gaussian"}}
+    n = 32
+    x = torch.from_numpy(synth.synth_crops(n, 256, 192, seed=1)).to(device)
+    tg = torch.from_numpy(synth.synth_heatmaps(n, 17, 64, 48, seed=2)).to(device)
+    tw = torch.ones(n, 17, 1, device=device)
+    tr = HRNetTrainer(cfg, sd, device=device, dtype=dtype)
+    heat = tr.forward(x[:8].contiguous())
+    loss8 = float(tr.loss_and_grad(heat, tg[:8].contiguous(), tw[:8].contiguous())[0].cpu()[0])
+    tr._tape = []
+    for _ in range(3):                                   # eager, capture, first replay
+        tr.train_step_graphed(x, tg, tw)
+    torch.cuda.synchronize()
+    steps = max(5, args.steps // 2)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = tr.train_step_graphed(x, tg, tw)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms = dt / steps * 1e3
+    from udp_pose_amd.hrnet_plan import HRNetProgram
+    flops = 3 * 2.0 * HRNetProgram(sd, synth.W32_EXTRA, 256, 192, "f32").macs_per_image() * n
+    peak = {"f32": 157.3, "bf16": 2500.0}[dtype]
+    tf = flops / (ms * 1e-3) / 1e12
+    out = {"workload": "w32 256x192 training step, batch=32 (config 3's per-GPU share), JointsMSELoss, Adam, hipGraph replay",
+           "value": round(n / ms * 1e3, 1), "unit": "images/s", "ms_per_step": round(ms, 3),
+           "dtype": dtype + (" activations (fp32 statistics, master weights, gradients, Adam): NO reference counterpart -- the "
+                             "reference trains in fp32" if dtype == "bf16" else " (the reference's precision)"),
+           "loss_after_steps": [float(v) for v in loss.cpu().numpy()], "steps_timed": steps,
+           "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+                        "note": "algorithmic FLOPs of the three conv passes (forward, input gradient, weight gradient) / wall time of the whole step"}}
+    del tr
+    return out, loss8, (x[:8].cpu(), tg[:8].cpu(), tw[:8].cpu())
+
+
+def other_configs(args, device, sd_w32):
+    """Configs 4, 5 and 3 of BASELINE.json, timed after the headline on rank 0 of a one-GPU run; every entry is
+    wrapped so that a failure shows up as an error string and never costs the headline line."""
+    out = {}
+    for model in ("w48", "rsn18"):
+        try:
+            out[model] = time_other_inference(model, args, device)
+        except Exception as e:                                      # noqa: BLE001
+            out[model] = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+    oracle_loss = None
+    for dtype in ("f32", "bf16"):
+        key = "train_w32_b32_" + dtype
+        try:
+            out[key], loss8, sample = time_train_step(dtype, args, device, sd_w32)
+            if oracle_loss is None and not args.no_cpu_baseline:
+                from oracle import train as o_train
+                torch.set_num_threads(min(usable_cpus(), int(os.environ.get("UDP_POSE_CPU_THREADS", "64"))))
+                t0 = time.time()
+                parts, _, _ = o_train.loss_and_grads({k: v.clone() for k, v in sd_w32.items()}, synth.W32_EXTRA, sample[0],
+                                                     sample[1], sample[2], "gaussian")
+                oracle_loss = (float(parts[0]), time.time() - t0)
+            if oracle_loss is not None:
+                out[key]["parity"] = {"step0_loss_8img": loss8, "cpu_oracle_loss_8img": oracle_loss[0],
+                                      "rel_err": abs(loss8 - oracle_loss[0]) / abs(oracle_loss[0]),
+                                      "note": "train-mode forward (batch statistics) + JointsMSELoss on 8 of the images vs oracle/train.py "
+                                              "(fwd + autograd bwd took %.1f s on the host)" % oracle_loss[1]}
+        except Exception as e:                                      # noqa: BLE001
+            out[key] = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -303,6 +419,7 @@ def main():
                     help="storage mode that is timed as `value` (default: the parity-grade split-fp16 mode)")
     ap.add_argument("--no-other-modes", action="store_true", help="do not time the bf16 mode after the headline one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="do not time W48 / RSN-18 / the training step after the headline")
     ap.add_argument("--no-graph", action="store_true", help="eager launches on lane streams instead of hipGraph replay")
     args = ap.parse_args()
 
@@ -366,7 +483,8 @@ def main():
                                    "(forward on 2N images + flip fuse + udp_decode_%s)" %
                                    (args.model, in_h, in_w, args.dtype, args.batch, "DARK" if tt == "gaussian" else "offset", tt),
                        "global_batch": world * args.batch, "parallelism": "replicas x%d (no data-path collective)" % world,
-                       "weights": "seeded synthetic, BN stats calibrated (tests/golden/bn_calib_%s_gaussian.npz)" % args.model}}
+                       "weights": "seeded synthetic, BN stats calibrated (tests/golden/bn_calib_%s_gaussian.npz)" % args.model,
+                       "inputs": "8 distinct seeded synthetic crops tiled to the batch + N(0, 0.01^2) noise per image, resident in HBM"}}
     if rank == 0:
         # the headline numbers are complete at this point: nothing below may keep the line from being printed
         try:
@@ -388,6 +506,13 @@ def main():
                 line["parity_vs_cpu_oracle"] = parity(sorted({args.dtype, "f32"} | set(other)), sd, x, c, s, ref, ref_hm, device)
             except Exception as e:                                  # noqa: BLE001
                 line.setdefault("cpu_baseline", {"error": "%s: %s" % (type(e).__name__, e)})
+        if world == 1 and args.model == "w32" and not args.no_other_configs:
+            del hp, net
+            torch.cuda.empty_cache()
+            try:
+                line["other_configs"] = other_configs(args, device, sd)
+            except Exception as e:                                  # noqa: BLE001
+                line["other_configs"] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

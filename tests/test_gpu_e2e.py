@@ -131,9 +131,14 @@ def test_w32_offset_head_matches_reference_heatmaps(golden_dir, dtype):
     np.testing.assert_allclose(got, g["out"], rtol=0, atol=1e-3)
 
 
-def test_w32_flip_test_and_decode_end_to_end(w32_gaussian):
-    """forward + mirrored forward + flip fuse + DARK decode vs the oracle pipeline (N=3)."""
+@pytest.mark.parametrize("dtype", ["f32", "f16x2"])
+def test_w32_flip_test_and_decode_end_to_end(w32_gaussian, dtype):
+    """forward + mirrored forward + flip fuse + DARK decode vs the oracle pipeline (N=3), in the reference's
+    precision and in the parity-grade split-fp16 mode (the bench headline's mode) under the same gates."""
     sd, net = w32_gaussian
+    if dtype != "f32":
+        net = MODELS["pose_hrnet"](_cfg(synth.W32_EXTRA, 17, "gaussian"), is_train=False, dtype=dtype)
+        net = net.load_state_dict(sd, strict=True).to("cuda").eval()
     x = torch.from_numpy(synth.synth_crops(3, 256, 192, seed=21))
     ref = ohrnet.hrnet_forward(sd, synth.W32_EXTRA, torch.cat([x, torch.flip(x, dims=[3])])).numpy()
     ref_hm = oflip.flip_fuse(ref[:3], ref[3:], oflip.COCO_FLIP_PAIRS, False)
@@ -159,8 +164,8 @@ def test_w32_flip_test_and_decode_end_to_end(w32_gaussian):
     err = np.abs(preds.cpu().numpy() - rp).max(axis=2)
     shift = _dark_shift(ref_hm)
     good = shift < 1.5
-    print("w32 fp32 end-to-end keypoint error px: median %.2g, p95 %.2g, max(well-conditioned %d/%d) %.2g, max(all) %.2g"
-          % (np.median(err), np.percentile(err, 95), good.sum(), good.size, err[good].max(), err.max()))
+    print("w32 %s end-to-end keypoint error px: median %.2g, p95 %.2g, max(well-conditioned %d/%d) %.2g, max(all) %.2g"
+          % (dtype, np.median(err), np.percentile(err, 95), good.sum(), good.size, err[good].max(), err.max()))
     assert good.mean() > 0.5
     assert err[good].max() < 2e-2
     assert np.median(err) < 1e-3        # north-star tolerance holds for the typical joint
@@ -520,3 +525,88 @@ def test_engine_buckets_the_box_count_and_bounds_its_caches(golden_dir, w32_gaus
     assert len(eng.model._io) <= eng.model.MAX_IO_SHAPES
     kp3b, _ = eng.infer_pose(frame, boxes[:3])               # evicted and rebuilt: same answer
     np.testing.assert_array_equal(kp3b, kp3)
+
+
+def test_engine_reruns_a_batch_that_leaves_fp16_range_in_fp32(golden_dir):
+    """the engine's default storage is split fp16 (|x| >= 65520 -> NaN).  Finiteness is checked
+    on the whole heat-map tensor on the device and such a batch is re-run with the same weights in fp32 (the
+    reference engine's precision): the result equals an fp32 engine's, bit for bit, and the retry is counted."""
+    from udp_pose_amd.config import default_config
+    from udp_pose_amd.pose_engine import UdpPsaPoseHip
+    sd = dict(_w32(golden_dir, "gaussian"))
+    for k in ("bn1.weight", "bn1.bias", "bn2.weight", "bn2.bias"):      # stem activations ~1e3, then ~1e6
+        sd[k] = sd[k] * 1.0e3
+    cfg = default_config()
+    cfg.MODEL.EXTRA = synth.W32_EXTRA
+    cfg.MODEL.IMAGE_SIZE = [192, 256]
+    cfg.MODEL.HEATMAP_SIZE = [48, 64]
+    cfg.DATASET.DATASET = "coco"
+    cfg.TEST.POST_PROCESS = True
+    frame = synth.synth_frame_u8(480, 640, seed=12)
+    boxes = synth.synth_boxes(3, seed=6)
+    eng = UdpPsaPoseHip("synthetic", None, "cuda", state_dict=sd, config=cfg)
+    assert eng.model.dtype == "f16x2"
+    kp, mv = eng.infer_pose(frame, boxes)
+    assert eng.fp32_retries == 1 and np.isfinite(kp).all() and np.isfinite(mv).all()
+    ref = UdpPsaPoseHip("synthetic", None, "cuda", state_dict=sd, config=cfg, dtype="f32")
+    kp32, mv32 = ref.infer_pose(frame, boxes)
+    assert ref.fp32_retries == 0
+    np.testing.assert_array_equal(kp, kp32)
+    np.testing.assert_array_equal(mv, mv32)
+    kpf, _ = eng.infer_pose(frame, boxes, flip_test=True)
+    kpf32, _ = ref.infer_pose(frame, boxes, flip_test=True)
+    np.testing.assert_array_equal(kpf, kpf32)
+
+
+def _batch_properties(net, x, n_img_check):
+    """Size-independent properties at a config's own batch: graph replay == eager launches, identical crops ->
+    identical maps, an image's maps do not depend on the batch it rides in, the in-kernel mirrored half == an
+    explicit forward of mirrored inputs -- all bit for bit."""
+    n = x.shape[0]
+    raw = net.raw_forward(x, flip_test=True).clone()
+    assert raw.shape[0] == 2 * n and torch.isfinite(raw).all()
+    assert torch.equal(raw, net.raw_forward(x, flip_test=True).clone())      # second call = graph replay
+    net.use_graph = False
+    eager = net.raw_forward(x, flip_test=True).clone()
+    net.use_graph = True
+    assert torch.equal(raw, eager)
+    assert torch.equal(raw[0], raw[4])                                        # x[4] is a copy of x[0]
+    k = n_img_check
+    one = net.raw_forward(x[k:k + 1].contiguous()).clone()
+    assert torch.equal(one[0], raw[k])
+    mirrored = net.raw_forward(torch.flip(x[:2], dims=[3]).contiguous()).clone()
+    assert torch.equal(mirrored, raw[n:n + 2])
+
+
+@pytest.mark.parametrize("dtype", ["f16x2"])
+def test_w48_batch32_properties(golden_dir, dtype):
+    """Config 4 at its own size (pose_hrnet_w48 384x288, N = 32, flip test on -> 64 images per launch sequence)
+    in the mode bench.py times it in."""
+    calib = dict(np.load(os.path.join(golden_dir, "bn_calib_w48_gaussian.npz")))
+    extra = synth.scaled_extra(48)
+    sd = synth.synth_state_dict(extra, 17, "gaussian", seed=2, bn_calib=calib)
+    net = MODELS["pose_hrnet"](_cfg(extra, 17, "gaussian"), is_train=False, dtype=dtype).load_state_dict(sd).to("cuda")
+    x = torch.from_numpy(synth.synth_crops(4, 384, 288, seed=6)).cuda().repeat(8, 1, 1, 1)      # N = 32
+    x[20:] += 0.01 * torch.randn(12, 3, 384, 288, device="cuda", generator=torch.Generator("cuda").manual_seed(2))
+    _batch_properties(net, x, 21)
+
+
+@pytest.mark.parametrize("dtype", ["f16x2"])
+def test_rsn18_offset_batch64_properties(golden_dir, dtype):
+    """Config 5 at its own size (RSN-18 256x192 with the 51-channel offset head, N = 64, flip test on) in the mode
+    bench.py times it in, then the offset decode on the fused maps against the oracle decode of the same maps."""
+    from udp_pose_amd.model import RSN18Hip
+    calib = dict(np.load(os.path.join(golden_dir, "bn_calib_rsn18_51.npz")))
+    sd = synth.synth_rsn18_state_dict(51, seed=4, bn_calib=calib)
+    net = RSN18Hip(51, dtype=dtype).load_state_dict(sd).to("cuda")
+    x = torch.from_numpy(synth.synth_crops(4, 256, 192, seed=8)).cuda().repeat(16, 1, 1, 1)     # N = 64
+    x[40:] += 0.01 * torch.randn(24, 3, 256, 192, device="cuda", generator=torch.Generator("cuda").manual_seed(3))
+    _batch_properties(net, x, 41)
+    raw = net.raw_forward(x, flip_test=True)
+    hm = flip_fuse(raw[:64], raw[64:], COCO_FLIP_PAIRS, True)
+    c, s = synth.synth_center_scale(64, seed=4)
+    rp, rm, _, ridx = odec.get_final_preds("offset", False, 4.0, hm.cpu().numpy().copy(), c, s)
+    preds, maxvals, _, idx = decode_device(hm, torch.from_numpy(c.astype(np.float64)),
+                                           torch.from_numpy(s.astype(np.float64)), "offset", False, 4.0, True)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+    np.testing.assert_allclose(preds.cpu().numpy(), rp, rtol=0, atol=1e-3)

@@ -520,6 +520,33 @@ def test_w32_train_step_at_config3_size(golden_dir):
     assert torch.isfinite(tr.flat).all() and tr.step_count == 1
 
 
+@pytest.mark.parametrize("n,h,w", [(48, 256, 192), (20, 256, 256)])
+def test_train_step_with_more_tiles_than_bn_partial_rows(golden_dir, n, h, w):
+    """the stem convs of a batch with more output tiles than udp_bn_rows_max() partial rows
+    (256x192 from 33 images, 256x256 -- the reference's MPII configs, BATCH_SIZE_PER_GPU 32 -- from 17) must fall
+    back to the separate statistics pass (UDP_ERR_WORKSPACE from the fused epilogue) instead of failing in
+    udp_bn_train_fwd_from_sums.  The step with BatchNorm fusion on equals the step with it off, bit for bit."""
+    calib = dict(np.load(os.path.join(golden_dir, "bn_calib_w32_gaussian.npz")))
+    sd0 = synth.synth_state_dict(synth.W32_EXTRA, 17, "gaussian", seed=0, bn_calib=calib)
+    cfg = {"MODEL": {"EXTRA": synth.W32_EXTRA, "NUM_JOINTS": 17, "TARGET_TYPE": "gaussian"}}
+    reps = (n + 3) // 4
+    x = torch.from_numpy(np.tile(synth.synth_crops(4, h, w, seed=51), (reps, 1, 1, 1))[:n]).cuda()
+    x = x + 0.02 * torch.randn(x.shape, generator=torch.Generator().manual_seed(5)).cuda()
+    tg = torch.from_numpy(synth.synth_heatmaps(n, 17, h // 4, w // 4, seed=52)).cuda()
+    tw = torch.ones(n, 17, 1, device="cuda")
+    assert (h // 2 // (2 if w == 192 else 1)) * n > _lib.lib().udp_bn_rows_max() or n * 128 > _lib.lib().udp_bn_rows_max()
+    out = {}
+    for fused in (True, False):
+        tr = HRNetTrainer(cfg, sd0, device="cuda", lr=1e-3)
+        tr.fuse_bn_stats = fused
+        loss = tr.train_step(x, tg, tw).cpu().numpy().copy()
+        out[fused] = (loss, tr.flat.clone())
+        assert np.isfinite(loss).all() and torch.isfinite(tr.flat).all()
+        del tr
+    np.testing.assert_array_equal(out[True][0], out[False][0])
+    assert torch.equal(out[True][1], out[False][1])
+
+
 def test_bf16_storage_training_tracks_fp32_and_learns():
     """dtype="bf16": activations / activation gradients stored in bf16 (fp32 statistics, master weights,
     gradients and Adam).  No reference counterpart (the reference trains in fp32): sanity gates only --

@@ -98,6 +98,29 @@ def main():
         hi = min(nwg, lo + max(1, nwg // 7))
         print("  wg %4d-%4d: " % (lo, hi - 1) + "  ".join("%s %.1f" % (nm, d[lo:hi, :, k].mean()) for k, nm in enumerate(names)))
     np.save(os.path.join(ROOT, "gpurun_out", "stamp_multi_stage%d.npy" % stage), s)
+    # per member (by the number of K chunks a workgroup stamped: chunk-boundary stamps 9/10 (c=1), 11/12 (c=2), 13/14 (c=4))
+    f = s.astype(np.float64) / 100.0
+    nch = 1 + (s[:, 0, 9] > 0) + (s[:, 0, 11] > 0) * 2 + (s[:, 0, 13] > 0) * 4      # 1, 2, 4, 8 chunks
+    for k in (1, 2, 4, 8):
+        m = nch == k
+        if not m.any():
+            continue
+        w = f[m]
+        print("  member with %d K chunks: %d workgroups, life %.1f us" % (k, m.sum(), life[m].mean()))
+        print("     prologue %.2f  dma-issue %.2f  first wait %.2f  barrier %.2f  loop %.2f  epilogue %.2f  drain %.2f" % tuple(
+            (w[:, :, j + 1] - w[:, :, j]).mean() for j in range(7)))
+        if k >= 2:
+            print("     chunk0 compute %.2f us (9 steps)   wait+barrier before chunk1 %.2f" % (
+                (w[:, :, 9] - w[:, :, 4]).mean(), (w[:, :, 10] - w[:, :, 9]).mean()))
+        if k >= 4:
+            print("     chunk1 compute %.2f   wait+barrier before chunk2 %.2f   chunks2-3 compute+waits %.2f" % (
+                (w[:, :, 11] - w[:, :, 10]).mean(), (w[:, :, 12] - w[:, :, 11]).mean(), (w[:, :, 5] - w[:, :, 12]).mean() if k == 4 else (w[:, :, 13] - w[:, :, 12]).mean()))
+        if k == 8:
+            print("     wait+barrier before chunk4 %.2f   chunks4-7 %.2f" % ((w[:, :, 14] - w[:, :, 13]).mean(), (w[:, :, 5] - w[:, :, 14]).mean()))
+        # per-wave spread inside a workgroup at the barrier before chunk 1 (who waits for whom)
+        if k >= 2:
+            arr = w[:, :, 9]
+            print("     arrival spread at the chunk-1 barrier (max-min over the 4 waves): mean %.2f us" % (arr.max(1) - arr.min(1)).mean())
     # concurrency per CU
     per = collections.defaultdict(list)
     for i in range(nwg):

@@ -857,10 +857,16 @@ __device__ __forceinline__ void conv_ws_body(const ConvParams& p, const int tile
     if (tap == 0) {
       // chunk c's DMA has landed (vector-memory operations complete in issue order: all but the 2*NB A loads
       // just issued, which may stay in flight; letting the previous step's stay in flight too changes nothing)
+      if (c == 1) UDP_STAMP(9);                           // (diagnostic builds only: chunk-boundary stamps of chunks 1, 2, 4)
+      if (c == 2) UDP_STAMP(11);
+      if (c == 4) UDP_STAMP(13);
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB) : "memory");
       if (s == 0) UDP_STAMP(3);
       __syncthreads();                                    // ... for every wave; nobody reads the other stage any more
       if (s == 0) UDP_STAMP(4);
+      if (c == 1) UDP_STAMP(10);
+      if (c == 2) UDP_STAMP(12);
+      if (c == 4) UDP_STAMP(14);
 #if !(UDP_WS_DBG & 4)
       if (c + 1 < nchunks) stage(c + 1, smem + ((c + 1) & 1) * stage_bytes);
 #endif

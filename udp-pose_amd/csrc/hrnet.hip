@@ -630,8 +630,11 @@ static int conv2d_fused_impl(const udp_conv_op* o, int dtype, int n, const void*
   if (rc) return rc;
   if (bn_ws) {
     // one partial row of 2*Cout doubles per tile (grid.x); the caller's workspace must hold them
-    if ((size_t)l.grid.x * 2 * o->cout > bn_ws_doubles)
-      return fail(UDP_ERR_WORKSPACE, "udp_conv2d_fused_bn: %u partial rows x %d doubles exceed the workspace", l.grid.x, 2 * o->cout);
+    // (and udp_bn_train_fwd_from_sums takes at most udp_bn_rows_max() rows: the caller falls back to the separate
+    // statistics pass on UDP_ERR_WORKSPACE either way)
+    if ((size_t)l.grid.x * 2 * o->cout > bn_ws_doubles || l.grid.x > (unsigned)udp_bn_rows_max())
+      return fail(UDP_ERR_WORKSPACE, "udp_conv2d_fused_bn: %u partial rows x %d doubles exceed the workspace or the %d-row limit",
+                  l.grid.x, 2 * o->cout, udp_bn_rows_max());
     *bn_rows = (int)l.grid.x;
   }
   return run_launch(l, s);
@@ -660,8 +663,9 @@ extern "C" int udp_conv2d_fused_group(udp_conv_item* items, int n_items, int dty
     if (rc == 1) rc = describe_conv(p, dtype, o->ks, o->stride, &L[j]);
     if (rc) return rc;
     if (it.bn_ws) {
-      if ((size_t)L[j].grid.x * 2 * o->cout > it.bn_ws_doubles)
-        return fail(UDP_ERR_WORKSPACE, "udp_conv2d_fused_group: member %d: %u partial rows x %d doubles exceed the workspace", j, L[j].grid.x, 2 * o->cout);
+      if ((size_t)L[j].grid.x * 2 * o->cout > it.bn_ws_doubles || L[j].grid.x > (unsigned)udp_bn_rows_max())
+        return fail(UDP_ERR_WORKSPACE, "udp_conv2d_fused_group: member %d: %u partial rows x %d doubles exceed the workspace or the %d-row limit",
+                    j, L[j].grid.x, 2 * o->cout, udp_bn_rows_max());
       it.bn_rows = (int)L[j].grid.x;
     }
   }

@@ -34,7 +34,8 @@ class PoseHighResolutionNetHip:
         self.cfg = cfg
         self.training = False
         self._trainer = None         # train.HRNetTrainer over the same weights (created by .train())
-        self._stale = False          # the trainer has stepped since the inference program was compiled
+        self._stale = False          # legacy flag (function.train sets it); the trainer's version counter decides
+        self._seen_version = 0       # trainer.version the inference program / state_dict were last synced at
         self.extra = _get(cfg, "MODEL", "EXTRA")
         self.num_joints = int(_get(cfg, "MODEL", "NUM_JOINTS"))
         self.target_type = _get(cfg, "MODEL", "TARGET_TYPE")
@@ -68,7 +69,7 @@ class PoseHighResolutionNetHip:
 
     def state_dict(self):
         """Reference-format state_dict; after training steps it is read back from the trainer's flat buffer."""
-        if self._trainer is not None and self._stale:
+        if self._trainer_moved():
             self._sync_from_trainer()
         return dict(self._sd or {})
 
@@ -107,7 +108,7 @@ class PoseHighResolutionNetHip:
         elif pretrained:
             raise ValueError("%s is not exist!" % pretrained)       # pose_hrnet.py:503-505
         self._sd = sd
-        self._trainer = None
+        self._trainer, self._seen_version = None, 0
         self._release()
         return self
 
@@ -131,9 +132,15 @@ class PoseHighResolutionNetHip:
         t = self.trainer()
         return [t.flat[:t._n_param]]
 
+    def _trainer_moved(self):
+        """True when the trainer has stepped (by whatever route: function.train, train_step, adam_step) since the
+        compiled inference program and ``_sd`` were last read from it."""
+        return self._trainer is not None and (self._stale or self._trainer.version != self._seen_version)
+
     def _sync_from_trainer(self):
         self._sd = self._trainer.state_dict()
         self._stale = False
+        self._seen_version = self._trainer.version
         self._release()
 
     def to(self, device):
@@ -216,7 +223,7 @@ class PoseHighResolutionNetHip:
             self.to(x.device)
         if not x.is_cuda:
             raise RuntimeError("udp-pose_amd has no CPU path: the input must live on the GPU")
-        if self._trainer is not None and self._stale:
+        if self._trainer_moved():
             self._sync_from_trainer()                      # weights moved since the program was compiled
         if x.dtype != torch.float32 or x.dim() != 4 or x.shape[1] != 3:
             raise ValueError("expected fp32 [N,3,H,W], got %s %s" % (x.dtype, tuple(x.shape)))

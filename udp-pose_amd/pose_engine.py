@@ -115,6 +115,7 @@ class UdpPsaPoseHip:
         self.model.load_state_dict(state_dict, strict=False)
         self.model.to(self._device)
         self.model.eval()
+        self._fallback, self.fp32_retries = None, 0     # fp32 twin for batches that leave fp16's range (infer_pose)
 
     def _box_to_center_scale(self, boxes, pixel_std=200):
         return box_to_center_scale(boxes, self.input_shape, pixel_std)
@@ -146,18 +147,40 @@ class UdpPsaPoseHip:
         xin, _ = self.model.io_buffers(nb, h, w, False)
         return warp_affine_device(frame, mats, (h, w), out=xin), cs
 
+    def _heatmaps(self, model, pose_input, n, flip_test, offset):
+        nb = pose_input.shape[0]
+        if flip_test:
+            xin, _ = model.io_buffers(nb, pose_input.shape[2], pose_input.shape[3], True)
+            xin.copy_(pose_input)
+            raw = model.raw_forward(xin, flip_test=True)
+            return flip_fuse(raw[:n], raw[nb:nb + n], self.flip_pairs, offset)
+        return model.raw_forward(pose_input)[:n]
+
+    def _f32_model(self):
+        """The same weights in the reference's precision (built on first need: an f16x2 forward left fp16's range)."""
+        if self._fallback is None:
+            m = MODELS[self.config.MODEL.NAME](self.config, is_train=False, dtype="f32")
+            m.load_state_dict(self.model.state_dict(), strict=False)
+            m.to(self._device)
+            m.eval()
+            self._fallback = m
+        return self._fallback
+
     @torch.no_grad()
     def infer_pose(self, img, boxes, flip_test=False):
         pose_input, cs = self._preprocess(img, boxes)
-        n, nb = cs.shape[0], pose_input.shape[0]
+        n = cs.shape[0]
         offset = self.config.MODEL.TARGET_TYPE == "offset"
-        if flip_test:
-            xin, _ = self.model.io_buffers(nb, pose_input.shape[2], pose_input.shape[3], True)
+        hm = self._heatmaps(self.model, pose_input, n, flip_test, offset)
+        if self.model.dtype != "f32" and not bool(torch.isfinite(hm).all()):
+            # split-fp16 storage turns an activation beyond fp16's range (|x| >= 65520) into NaN / Inf.  Checked on
+            # the WHOLE heat-map tensor (every channel of an offset head too; a max reduction can drop NaNs), and the
+            # batch is re-run in fp32 -- the range of the reference engine -- instead of returning garbage.
+            self.fp32_retries += 1
+            fb = self._f32_model()
+            xin, _ = fb.io_buffers(pose_input.shape[0], pose_input.shape[2], pose_input.shape[3], False)
             xin.copy_(pose_input)
-            raw = self.model.raw_forward(xin, flip_test=True)
-            hm = flip_fuse(raw[:n], raw[nb:nb + n], self.flip_pairs, offset)
-        else:
-            hm = self.model.raw_forward(pose_input)[:n]
+            hm = self._heatmaps(fb, xin, n, flip_test, offset)
         center = torch.from_numpy(cs[:, :2].astype(np.float64))
         scale = torch.from_numpy(cs[:, 2:].astype(np.float64))
         post = bool(self.config.TEST.POST_PROCESS) and not offset
@@ -165,10 +188,7 @@ class UdpPsaPoseHip:
                                              float(self.config.LOSS.KPD), cs_is_f32=True, want_idx=False)
         kp, mv = preds.cpu().numpy(), maxvals.cpu().numpy()
         if not np.isfinite(mv).all():
-            # split-fp16 storage turns an activation beyond fp16's range (|x| >= 65520) into NaN -- surfaced here
-            # instead of returning garbage keypoints (the fp32 mode has the range of the reference)
-            raise FloatingPointError("non-finite heat-maps (dtype=%s): an activation left the storage type's range; "
-                                     "run the engine with dtype='f32'" % self.model.dtype)
+            raise FloatingPointError("non-finite heat-maps in fp32 too: the weights or the frame hold non-finite values")
         return (kp if post else kp.astype(np.float32)), mv
 
     def draw_keypoints(self, image, keypoints, radius=1):

@@ -121,13 +121,15 @@ class HRNetTrainer:
         self._zeros = torch.zeros(1024, dtype=torch.float32, device=self.device)      # zero bias rows
         # one BatchNorm workspace per branch slot: the branches of a module run in lock step (_blocks_lockstep), a
         # conv's epilogue leaves its partial rows in its slot until the multi-tensor BatchNorm call has read them
-        self._bn_wss = [torch.zeros(_lib.lib().udp_bn_workspace_doubles(1024), dtype=torch.float64, device=self.device)
+        bn_c = max([shapes[k][0] for k in self._keys if len(shapes[k]) == 1] + [64])     # widest BatchNorm of this net
+        self._bn_wss = [torch.zeros(_lib.lib().udp_bn_workspace_doubles(bn_c), dtype=torch.float64, device=self.device)
                         for _ in range(4)]
         self._bn_ws = self._bn_wss[0]
         self.bn_multi = os.environ.get("UDP_POSE_NO_BN_MULTI") is None           # A/B knob
         self.conv_multi = os.environ.get("UDP_POSE_NO_CONV_MULTI") is None       # A/B knob (merged branch convs)
         self._loss = torch.zeros(2, dtype=torch.float64, device=self.device)
         self._graphs, self._warm, self._coef = {}, set(), None            # train_step_graphed
+        self.version = 0                      # bumped by every optimizer step (the owning model's staleness check)
         self._tape = []
         self.fuse_bn_stats = os.environ.get("UDP_POSE_NO_BN_FUSION") is None     # A/B knob
         # gradient buckets for the all-reduce (~25 MB each): consecutive parameters of the flat
@@ -635,6 +637,7 @@ class HRNetTrainer:
         """optimizer.step(): torch.optim.Adam(lr) on the flat parameter buffer (utils.py:70-74).
         ``grad_scale``: 1/world_size after the SUM all-reduce of the gradient."""
         self.step_count += 1
+        self.version += 1                                   # owners compare it with the version they last read
         _lib.check(_lib.lib().udp_adam_step(self.flat.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(),
                                             self.exp_avg_sq.data_ptr(), self._n_param, self.lr, self.betas[0],
                                             self.betas[1], self.eps, self.step_count, float(grad_scale),
@@ -667,9 +670,9 @@ class HRNetTrainer:
                 self._coef_host = [torch.zeros(2, dtype=torch.float32).pin_memory() for _ in range(4)]
                 self._coef_done = [None] * 4
             gx, gt, gw = x.clone(), target.contiguous().clone(), target_weight.contiguous().clone()
+            torch.cuda.synchronize()             # the last replay of an evicted graph may still be running
             while len(self._graphs) >= 2:
                 self._graphs.pop(next(iter(self._graphs)))
-            torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 heat = self.forward(gx)
@@ -691,6 +694,7 @@ class HRNetTrainer:
         self._coef_done[slot] = torch.cuda.Event()
         self._coef_done[slot].record()
         graph.replay()
+        self.version += 1
         return self._loss
 
     def train_step(self, x, target, target_weight, world_size=1):
