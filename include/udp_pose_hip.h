@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UDP_POSE_ABI_VERSION 15
+#define UDP_POSE_ABI_VERSION 16
 
 enum udp_status {
   UDP_OK = 0,
@@ -46,6 +46,13 @@ enum udp_dtype { UDP_F32 = 0, UDP_BF16 = 1, UDP_F16X2 = 2 };
 
 /* ABI version of the loaded library (== UDP_POSE_ABI_VERSION it was built with). */
 int udp_abi_version(void);
+/* UDP_F16X2 range guard.  Split-fp16 storage has fp16's range: a value of magnitude >= 65520 (or a NaN) about to be
+ * stored raises a device-side flag in the kernel that produced it -- at the source, because a NaN does not survive
+ * the next ReLU and a finiteness test of the heat-maps can miss the event.  Waits for `stream`, then returns 1 if
+ * any split-fp16 store since the last reset left the range, 0 if none, < 0 on error; reset != 0 clears the flag.
+ * The caller re-runs such a batch in UDP_F32 (udp_pose_amd.pose_engine does; the reference engine is fp32,
+ * deep_hrnet/pose_engine.py:99-127). */
+int udp_f16x2_overflow(void* stream, int reset);
 /* Message of the last error on this thread ("" if none). */
 const char* udp_last_error(void);
 
@@ -118,7 +125,13 @@ typedef struct udp_conv_op {
                               weight-stationary kernel -- 1 KiB blocks [tap][cin chunk of 32][cout pair of 32]
                               [block nb of 16][plane hi|lo], a block = 64 lanes x 8 fp16: lane kg*16 + li holds
                               w[tap][32*pair + 8*(li>>2) + 4*nb + (li&3)][32*chunk + 8*kg .. +7] (cin zero-padded to
-                              a multiple of 32).  udp_pose_amd.f16x2.pack_weights_ws builds it. */
+                              a multiple of 32).  The stored numbers are the weights times 2^wexp: plane hi =
+                              fp16(w * 2^wexp), plane lo = fp16(w * 2^wexp - hi) (the plain residual, NOT scaled by 2^11
+                              as activations are).  udp_pose_amd.f16x2.pack_weights_ws builds it. */
+  int32_t wexp;            /* wfmt 1: power-of-two scale of the stored weights, chosen so that max |w| * 2^wexp lies in
+                              [2^13, 2^14) (|wexp| <= 40; 0 for an all-zero tensor).  The kernel keeps one fp32
+                              accumulator of conv * 2^wexp and multiplies by 2^-wexp in its epilogue. */
+  int32_t reserved0;
 } udp_conv_op;
 
 typedef struct udp_hrnet udp_hrnet; /* opaque */

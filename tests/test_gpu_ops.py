@@ -66,7 +66,8 @@ def _conv_case(dtype, ks, stride, cin, cout, h, w, n, relu, res, nup, nchw_out=F
     bp = torch.zeros(cout_pad)
     bp[:cout] = bias
     nhwc = lambda t: (f16x2.encode(t.permute(0, 2, 3, 1)) if h2 else t.permute(0, 2, 3, 1).contiguous()).cuda()
-    d_x, d_w, d_b = nhwc(x), (f16x2.pack_weights_ws(wp) if ws else f16x2.encode(wp) if h2 else wp).cuda(), bp.cuda()
+    wsp, wexp = f16x2.pack_weights_ws(wp) if ws else (None, 0)
+    d_x, d_w, d_b = nhwc(x), (wsp if ws else f16x2.encode(wp) if h2 else wp).cuda(), bp.cuda()
     d_r = nhwc(r) if r is not None else None
     d_u = [nhwc(t) for t in ups] + [None] * (3 - nup)
     op = _lib.ConvOp()
@@ -74,7 +75,7 @@ def _conv_case(dtype, ks, stride, cin, cout, h, w, n, relu, res, nup, nchw_out=F
     op.cin, op.cout, op.cout_pad = cin, cout, cout_pad
     op.hin, op.win, op.hout, op.wout = h, w, ho, wo
     op.n_up = nup
-    op.wfmt = int(ws)
+    op.wfmt, op.wexp = int(ws), wexp
     for u in range(nup):
         op.up_shift[u] = u + 1
     if nchw_out:

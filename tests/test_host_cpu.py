@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libudp_pose_hip.so does not export %s" % name
     assert declared == set(_lib.EXPORTS)
-    assert lib.udp_abi_version() == _lib.ABI_VERSION == 15
+    assert lib.udp_abi_version() == _lib.ABI_VERSION == 16
 
 
 def test_argument_validation_without_gpu():
@@ -239,8 +239,15 @@ def test_f16x2_host_encoding_and_fragment_major_weights():
     # fragment-major layout: 3x3, 40 real couts padded to 64, 48 cin padded to 64
     taps, cout_pad, cin = 9, 64, 48
     w = torch.randn(taps, cout_pad, cin, generator=g) * 0.05
-    packed = f16x2.pack_weights_ws(w).view(torch.float16).reshape(taps, 2, 2, 2, 2, 64, 8)   # tap, chunk, pair, nb, plane, lane, j
-    enc = f16x2.encode(torch.nn.functional.pad(w, (0, 16)))     # [tap, cout, plane, k]
+    packed, wexp = f16x2.pack_weights_ws(w)
+    packed = packed.view(torch.float16).reshape(taps, 2, 2, 2, 2, 64, 8)   # tap, chunk, pair, nb, plane, lane, j
+    # stored scaled by 2^wexp (largest magnitude in [2^13, 2^14)): hi = fp16(w'), lo = fp16(w' - hi), the plain residual
+    assert wexp == f16x2.weight_exponent(w) and 2.0 ** 13 <= float(w.abs().max()) * 2.0 ** wexp < 2.0 ** 14
+    ws_ = torch.nn.functional.pad(w, (0, 16)) * 2.0 ** wexp
+    hi = ws_.to(torch.float16)
+    enc = torch.stack([hi, (ws_ - hi.float()).to(torch.float16)], dim=2)     # [tap, cout, plane, k]
+    assert float(((enc[:, :, 0].float() + enc[:, :, 1].float()) * 2.0 ** -wexp - torch.nn.functional.pad(w, (0, 16))).abs().max()) <= 2.0 ** -22 * float(w.abs().max())
+    assert f16x2.weight_exponent(torch.zeros(3)) == 0 and f16x2.weight_exponent(torch.tensor([1.0])) == 13
     rng = np.random.default_rng(1)
     for _ in range(200):
         tap, c, pair, nb, plane, lane, j = (int(rng.integers(n)) for n in (taps, 2, 2, 2, 2, 64, 8))

@@ -53,7 +53,8 @@ def main():
     net.use_graph = False
     hp = bench.HotPath(net, batch, torch.device("cuda", 0), seed=1)
     lib = _lib.lib()
-    lib.udp_debug_set_stamps.argtypes = [C.c_void_p]
+    set_stamps = lib.udp_debug_set_stamps_ws
+    set_stamps.argtypes = [C.c_void_p]
     stamps = torch.zeros(8192 * 4 * 16, dtype=torch.int64, device="cuda")
     for _ in range(2):
         try:
@@ -61,7 +62,7 @@ def main():
         except Exception as e:          # the truncated program has no output op: the decode after it may complain
             print("step raised", type(e).__name__, e)
     torch.cuda.synchronize()
-    _lib.check(lib.udp_debug_set_stamps(C.c_void_p(stamps.data_ptr())))
+    _lib.check(set_stamps(C.c_void_p(stamps.data_ptr())))
     try:
         hp.step()
     except Exception as e:
@@ -71,61 +72,45 @@ def main():
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     np.save(os.path.join(ROOT, "gpurun_out", "stamp_multi_stage%d_raw.npy" % stage), s[: 4096])
     print("group members:", cut.get("ops"))
-    # earlier launches of the truncated program stamped the same buffer: the last launch's entries are the newest
-    newest = s[:, 0, 0].max()
-    live = s[:, 0, 0] > newest - 30000
-    nwg = int(np.argmin(live)) if not live.all() else len(live)
-    s = s[:nwg]
-    t0 = s[:, :, 0].min()
-    start = (s[:, :, 0].min(axis=1) - t0) / 100.0      # s_memtime ticks at 100 MHz -> us
-    end = (s[:, :, 7].max(axis=1) - t0) / 100.0
-    hw = s[:, 0, 8]
-    cu = ((hw >> 32) & 0xF) * 1024 + ((hw >> 13) & 7) * 16 * 2 + ((hw >> 12) & 1) * 16 + ((hw >> 8) & 0xF)
-    print("%d workgroups, launch span %.1f us, %d distinct CUs" % (nwg, end.max(), len(set(cu.tolist()))))
-    # member boundaries: members are laid out back to back; a member's workgroups have the same number of
-    # MFMA steps -> recover the boundaries from the jumps in (stamp5 - stamp4) is fragile; print deciles instead
-    life = end - start
-    order = np.arange(nwg)
-    for lo in range(0, nwg, max(1, nwg // 14)):
-        hi = min(nwg, lo + max(1, nwg // 14))
-        print("  wg %4d-%4d: start %6.1f..%6.1f us  life mean %5.1f (p10 %5.1f p90 %5.1f)  end max %6.1f" % (
-            lo, hi - 1, start[lo:hi].min(), start[lo:hi].max(), life[lo:hi].mean(),
-            np.percentile(life[lo:hi], 10), np.percentile(life[lo:hi], 90), end[lo:hi].max()))
-    # phase breakdown of a wave (cycles of the 100 MHz counter -> us)
-    d = np.diff(s[:, :, :8].astype(np.float64), axis=2) / 100.0
-    names = ["prologue", "issue DMA c0", "wait DMA c0", "barrier", "MFMA loop", "epilogue issue", "store drain"]
-    for lo in range(0, nwg, max(1, nwg // 7)):
-        hi = min(nwg, lo + max(1, nwg // 7))
-        print("  wg %4d-%4d: " % (lo, hi - 1) + "  ".join("%s %.1f" % (nm, d[lo:hi, :, k].mean()) for k, nm in enumerate(names)))
-    np.save(os.path.join(ROOT, "gpurun_out", "stamp_multi_stage%d.npy" % stage), s)
-    # per member (by the number of K chunks a workgroup stamped: chunk-boundary stamps 9/10 (c=1), 11/12 (c=2), 13/14 (c=4))
-    f = s.astype(np.float64) / 100.0
-    nch = 1 + (s[:, 0, 9] > 0) + (s[:, 0, 11] > 0) * 2 + (s[:, 0, 13] > 0) * 4      # 1, 2, 4, 8 chunks
+    analyse(s)
+
+
+def analyse(s, ghz=2.4):
+    """Per member of the last launch: where a workgroup's lifetime goes.  s_memtime counts shader cycles and every XCD
+    has its own counter (offsets of 1e11 between XCDs), so only differences inside one wave / one XCD are used; a
+    stamp slot belongs to the last launch iff it lies between the wave's first and last stamp.  us at `ghz`."""
+    s = s.astype(np.float64)
+    xcc = (s[:, 0, 8].astype(np.int64) >> 32) & 0xF
+    t0 = s[:, 0, 0]
+    live = np.zeros(len(s), bool)
+    for x in range(8):                               # the newest 170 us on each XCD's own clock = the last launch
+        m = (xcc == x) & (t0 > 0)
+        if m.any():
+            live |= m & (t0 > t0[m].max() - 400000)
+    w = s[live] / (ghz * 1e3)
+    ok = lambda k: (w[:, 0, k] >= w[:, 0, 0]) & (w[:, 0, k] <= w[:, 0, 7])
+    nch = 1 + ok(9) + ok(11) * 2 + ok(13) * 4        # K chunks stamped: 1, 2, 4, 8
+    life = w[:, :, 7].max(1) - w[:, :, 0].min(1)
+    print("%d workgroups of the last launch (us at %.1f GHz)" % (live.sum(), ghz))
     for k in (1, 2, 4, 8):
         m = nch == k
         if not m.any():
             continue
-        w = f[m]
-        print("  member with %d K chunks: %d workgroups, life %.1f us" % (k, m.sum(), life[m].mean()))
-        print("     prologue %.2f  dma-issue %.2f  first wait %.2f  barrier %.2f  loop %.2f  epilogue %.2f  drain %.2f" % tuple(
-            (w[:, :, j + 1] - w[:, :, j]).mean() for j in range(7)))
+        v = w[m]
+        d = lambda a, b: (v[:, :, b] - v[:, :, a]).mean()
+        print(" member with %d K chunks: %d workgroups, life %.1f us | start->DMA issue %.2f  index math + load issue %.2f  "
+              "first wait %.2f  barrier %.2f  loop %.2f  epilogue %.2f  store drain %.2f" % (
+                  k, m.sum(), life[m].mean(), d(0, 1), d(1, 2), d(2, 3), d(3, 4), d(4, 5), d(5, 6), d(6, 7)))
         if k >= 2:
-            print("     chunk0 compute %.2f us (9 steps)   wait+barrier before chunk1 %.2f" % (
-                (w[:, :, 9] - w[:, :, 4]).mean(), (w[:, :, 10] - w[:, :, 9]).mean()))
+            print("    chunk 0 (9 steps) %.2f | wait + barrier before chunk 1 %.2f | arrival spread of the 4 waves there %.2f" % (
+                d(4, 9), d(9, 10), (v[:, :, 9].max(1) - v[:, :, 9].min(1)).mean()))
+        if k == 2:
+            print("    chunk 1 %.2f" % d(10, 5))
         if k >= 4:
-            print("     chunk1 compute %.2f   wait+barrier before chunk2 %.2f   chunks2-3 compute+waits %.2f" % (
-                (w[:, :, 11] - w[:, :, 10]).mean(), (w[:, :, 12] - w[:, :, 11]).mean(), (w[:, :, 5] - w[:, :, 12]).mean() if k == 4 else (w[:, :, 13] - w[:, :, 12]).mean()))
+            print("    chunk 1 %.2f | wait + barrier before chunk 2 %.2f | %s %.2f" % (
+                d(10, 11), d(11, 12), "chunks 2-3" if k == 4 else "chunks 2-3", d(12, 5) if k == 4 else d(12, 13)))
         if k == 8:
-            print("     wait+barrier before chunk4 %.2f   chunks4-7 %.2f" % ((w[:, :, 14] - w[:, :, 13]).mean(), (w[:, :, 5] - w[:, :, 14]).mean()))
-        # per-wave spread inside a workgroup at the barrier before chunk 1 (who waits for whom)
-        if k >= 2:
-            arr = w[:, :, 9]
-            print("     arrival spread at the chunk-1 barrier (max-min over the 4 waves): mean %.2f us" % (arr.max(1) - arr.min(1)).mean())
-    # concurrency per CU
-    per = collections.defaultdict(list)
-    for i in range(nwg):
-        per[int(cu[i])].append((start[i], end[i], i))
-    print("workgroups per CU: min %d max %d" % (min(len(v) for v in per.values()), max(len(v) for v in per.values())))
+            print("    wait + barrier before chunk 4 %.2f | chunks 4-7 %.2f" % (d(13, 14), d(14, 5)))
 
 
 if __name__ == "__main__":

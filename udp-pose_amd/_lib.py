@@ -16,7 +16,7 @@ DTYPES = {"f32": UDP_F32, "bf16": UDP_BF16, "f16x2": UDP_F16X2}
 UDP_OP_STEM, UDP_OP_CONV, UDP_OP_FUSE, UDP_OP_STEM7, UDP_OP_MAXPOOL, UDP_OP_BILINEAR = 0, 1, 2, 3, 4, 5
 UDP_OP_PSA_POOL, UDP_OP_PSA_MLP, UDP_OP_PSA_SCALE, UDP_OP_PSA_SP, UDP_OP_BLOCK = 6, 7, 8, 9, 10
 UDP_BUF_NONE, UDP_BUF_OUTPUT = -1, -2
-ABI_VERSION = 15
+ABI_VERSION = 16
 MAX_LANES, MAX_WAIT = 4, 8
 
 
@@ -54,7 +54,7 @@ class ConvOp(C.Structure):
         ("res_coff", C.c_int32), ("res_pitch", C.c_int32),
         ("lane", C.c_int32), ("n_wait", C.c_int32), ("wait_op", C.c_int32 * 8),
         ("w2_off", C.c_int64), ("b2_off", C.c_int64),
-        ("group", C.c_int32), ("wfmt", C.c_int32),
+        ("group", C.c_int32), ("wfmt", C.c_int32), ("wexp", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -73,6 +73,7 @@ class PackDesc(C.Structure):
 _P = C.c_void_p
 _SIGS = {
     "udp_abi_version": (C.c_int, []),
+    "udp_f16x2_overflow": (C.c_int, [C.c_void_p, C.c_int]),
     "udp_last_error": (C.c_char_p, []),
     "udp_hrnet_create": (C.c_int, [C.POINTER(ConvOp), C.c_int, C.POINTER(C.c_int64), C.c_int, _P,
                                    C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
@@ -161,6 +162,14 @@ def lib():
 def check(rc):
     if rc != UDP_OK:
         raise UdpPoseError(rc, lib().udp_last_error().decode("utf-8", "replace"))
+
+
+def f16x2_overflow(reset=True):
+    """udp_f16x2_overflow on torch's current stream: True if a split-fp16 store since the last reset left fp16's range."""
+    rc = lib().udp_f16x2_overflow(stream_ptr(), int(bool(reset)))
+    if rc < 0:
+        raise UdpPoseError(rc, lib().udp_last_error().decode("utf-8", "replace"))
+    return rc != 0
 
 
 def ptr(t):

@@ -33,6 +33,29 @@ inline int fail(int code, const char* fmt, ...) {
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// Split-fp16 ("f16x2") range guard.  fp16 tops out at 65504: a value of magnitude >= 65520 splits into hi = inf, and
+// the NaN that grows out of it downstream does not survive a ReLU (max(NaN, 0) = 0), so a finiteness test of the
+// final heat-maps can miss it.  Every kernel that WRITES split-fp16 values therefore raises this flag at the source
+// (one per translation unit; udp_f16x2_overflow() ORs them).  m = the largest magnitude about to be split (NaN
+// compares false, so `!(m < limit)` catches it too).
+static __device__ int g_h2_overflow;
+__device__ __forceinline__ void h2_range_check(float m) {
+  if (!(m < 65520.f)) g_h2_overflow = 1;
+}
+// flag of the calling translation unit after `s` has drained; cleared when `reset`
+static inline int h2_overflow_fetch(hipStream_t s, int reset, int* flag) {
+  int v = 0;
+  UDP_HIP_CHECK(hipMemcpyFromSymbolAsync(&v, HIP_SYMBOL(g_h2_overflow), sizeof(int), 0, hipMemcpyDeviceToHost, s));
+  UDP_HIP_CHECK(hipStreamSynchronize(s));
+  if (v && reset) {
+    const int z = 0;
+    UDP_HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_h2_overflow), &z, sizeof(int), 0, hipMemcpyHostToDevice, s));
+    UDP_HIP_CHECK(hipStreamSynchronize(s));
+  }
+  *flag |= v != 0;
+  return UDP_OK;
+}
+
 // Parameters of one fused conv launch (device-visible, passed by value).
 struct ConvParams {
   const void* in;
@@ -58,6 +81,7 @@ struct ConvParams {
   int flip_from;         // stem only: images >= flip_from read image (n - flip_from) mirrored in x
   int sbuf;              // conv_mfma_kernel: one stage buffer instead of two (set by conv_choose_tile)
   int wfmt;              // udp_conv_op.wfmt: 1 = fragment-major split-fp16 weights (conv_ws_h2_kernel)
+  int wexp;              // udp_conv_op.wexp: those weights are stored scaled by 2^wexp
   double* bn_ws;         // training: per-workgroup BatchNorm partial sums of the output, [tile][2*Cout] (or null)
 };
 
@@ -96,4 +120,11 @@ struct Launch {
   int ws_cp = 0;       // weight-stationary member: its cout pairs per workgroup
   ConvParams p;
 };
+// conv_ws.hip: the weight-stationary split-fp16 convs (tile choice + kernel of one conv; merged launch of 2..4)
+int describe_conv_ws(ConvParams p, int ks, int stride, Launch* out, bool grouped = false);
+int describe_ws_multi(const Launch* members, int n, ConvMulti* m, Launch* out);
+int ws_set_stamps(unsigned long long* dev_buf);      // diagnostic builds (-DUDP_STAMPS) only
+int conv_h2_overflow(hipStream_t s, int reset, int* flag);       // conv.hip / conv_ws.hip / psa.hip: their g_h2_overflow
+int conv_ws_h2_overflow(hipStream_t s, int reset, int* flag);
+int psa_h2_overflow(hipStream_t s, int reset, int* flag);
 }  // namespace udp

@@ -157,6 +157,15 @@ static int validate_op(const udp_hrnet* h, const udp_conv_op& o, int idx) {
 extern "C" int udp_abi_version(void) { return UDP_POSE_ABI_VERSION; }
 extern "C" const char* udp_last_error(void) { return err_buf(); }
 
+extern "C" int udp_f16x2_overflow(void* stream, int reset) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  int flag = 0;
+  int rc = conv_h2_overflow(s, reset, &flag);
+  if (!rc) rc = conv_ws_h2_overflow(s, reset, &flag);
+  if (!rc) rc = psa_h2_overflow(s, reset, &flag);
+  return rc ? rc : flag;
+}
+
 extern "C" int udp_hrnet_create(const udp_conv_op* ops, int n_ops, const int64_t* buf_elems, int n_bufs,
                                 const void* weights_dev, size_t weights_bytes, int dtype, int in_h, int in_w,
                                 int out_channels, udp_hrnet** out) {
@@ -251,6 +260,7 @@ static int describe_all(const udp_hrnet* h, const float* in, int n, int flip, ch
     p.CoutPad = o.cout_pad;
     p.relu = o.relu;
     p.wfmt = o.wfmt;
+    p.wexp = o.wexp;
     p.flip_from = flip ? n : B;
     const bool is_stem = o.kind == UDP_OP_STEM || o.kind == UDP_OP_STEM7;
     p.in_pitch = o.in_pitch ? o.in_pitch : o.cin;
@@ -593,6 +603,7 @@ static int conv2d_params(const udp_conv_op* o, int dtype, int n, const void* in,
   p.CoutPad = o->cout_pad;
   p.relu = o->relu;
   p.wfmt = o->wfmt;
+  p.wexp = o->wexp;
   p.flip_from = n;
   p.in_pitch = o->in_pitch ? o->in_pitch : o->cin;
   p.in_coff = o->in_coff;

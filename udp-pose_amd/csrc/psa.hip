@@ -40,6 +40,7 @@ __device__ __forceinline__ void stx(void* base, size_t px, int C, int c, float v
   if constexpr (std::is_same<T, H2>::value) {
     _Float16* q = reinterpret_cast<_Float16*>(base) + px * 2 * C + c;
     const _Float16 hi = (_Float16)v;
+    h2_range_check(__builtin_fabsf(v));
     q[0] = hi;
     q[C] = (_Float16)((v - (float)hi) * kLoScale);
   } else {
@@ -285,5 +286,7 @@ int describe_psa(const ConvParams& p, int dtype, int kind, Launch* out) {
   }
   return fail(UDP_ERR_ARG, "describe_psa: kind %d", kind);
 }
+
+int psa_h2_overflow(hipStream_t s, int reset, int* flag) { return h2_overflow_fetch(s, reset, flag); }
 
 }  // namespace udp

@@ -120,10 +120,11 @@ class HRNetProgram:
         cout_pad = _round_up(cout, 32)
         wp = torch.zeros(kh * kw, cout_pad, cin, dtype=torch.float32)
         wp[:, :cout] = w.permute(2, 3, 0, 1).reshape(kh * kw, cout, cin)
+        self._wexp = 0
         if ws:
             from .f16x2 import pack_weights_ws
-            encode_weights(wp, self.dtype)                     # range check only
-            wbytes = pack_weights_ws(wp).numpy().tobytes()
+            packed, self._wexp = pack_weights_ws(wp)           # scaled by 2^wexp: any finite magnitude fits
+            wbytes = packed.numpy().tobytes()
         else:
             wbytes = encode_weights(wp, self.dtype)
         bp = torch.zeros(cout_pad, dtype=torch.float32)
@@ -147,7 +148,7 @@ class HRNetProgram:
         out = None if to_output else self._new(cout, ho, wo)
         self._ops.append(dict(kind=_lib.UDP_OP_CONV, ks=ks, stride=stride, relu=int(relu), cin=cin, cout=cout,
                               cout_pad=cout_pad, hin=x.h, win=x.w, hout=ho, wout=wo, inp=x, out=out, res=res,
-                              ups=list(ups), w_off=w_off, b_off=b_off, name=conv, group=group, wfmt=int(ws)))
+                              ups=list(ups), w_off=w_off, b_off=b_off, name=conv, group=group, wfmt=int(ws), wexp=self._wexp))
         return out
 
     def _next_group(self):
@@ -410,7 +411,7 @@ class HRNetProgram:
             o.in_buf = _lib.UDP_BUF_NONE if op["inp"] is None else self._phys[op["inp"].id]
             o.out_buf = _lib.UDP_BUF_OUTPUT if op["out"] is None else self._phys[op["out"].id]
             o.res_buf = _lib.UDP_BUF_NONE if op["res"] is None else self._phys[op["res"].id]
-            for f in ("in_coff", "in_pitch", "out_coff", "out_pitch", "res_coff", "res_pitch", "w2_off", "b2_off", "group", "wfmt"):
+            for f in ("in_coff", "in_pitch", "out_coff", "out_pitch", "res_coff", "res_pitch", "w2_off", "b2_off", "group", "wfmt", "wexp"):
                 setattr(o, f, op.get(f, 0))
             o.lane = op["lane"]
             o.n_wait = len(op["wait"])

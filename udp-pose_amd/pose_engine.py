@@ -172,10 +172,11 @@ class UdpPsaPoseHip:
         n = cs.shape[0]
         offset = self.config.MODEL.TARGET_TYPE == "offset"
         hm = self._heatmaps(self.model, pose_input, n, flip_test, offset)
-        if self.model.dtype != "f32" and not bool(torch.isfinite(hm).all()):
-            # split-fp16 storage turns an activation beyond fp16's range (|x| >= 65520) into NaN / Inf.  Checked on
-            # the WHOLE heat-map tensor (every channel of an offset head too; a max reduction can drop NaNs), and the
-            # batch is re-run in fp32 -- the range of the reference engine -- instead of returning garbage.
+        if self.model.dtype == "f16x2" and _lib.f16x2_overflow(reset=True):
+            # split-fp16 storage has fp16's range (|x| < 65520).  The kernels flag a value that leaves it where it is
+            # produced (udp_f16x2_overflow: the NaN it turns into downstream would not survive the next ReLU, so a
+            # finiteness test of the heat-maps can miss it) and the batch is re-run in fp32 -- the precision and
+            # range of the reference engine -- instead of returning garbage.
             self.fp32_retries += 1
             fb = self._f32_model()
             xin, _ = fb.io_buffers(pose_input.shape[0], pose_input.shape[2], pose_input.shape[3], False)
