@@ -525,7 +525,7 @@ def test_train_step_with_more_tiles_than_bn_partial_rows(golden_dir, n, h, w):
     """the stem convs of a batch with more output tiles than udp_bn_rows_max() partial rows
     (256x192 from 33 images, 256x256 -- the reference's MPII configs, BATCH_SIZE_PER_GPU 32 -- from 17) must fall
     back to the separate statistics pass (UDP_ERR_WORKSPACE from the fused epilogue) instead of failing in
-    udp_bn_train_fwd_from_sums.  The step with BatchNorm fusion on equals the step with it off, bit for bit."""
+    udp_bn_train_fwd_from_sums.  The step with BatchNorm fusion on equals the step with it off up to the summation order of the statistics."""
     calib = dict(np.load(os.path.join(golden_dir, "bn_calib_w32_gaussian.npz")))
     sd0 = synth.synth_state_dict(synth.W32_EXTRA, 17, "gaussian", seed=0, bn_calib=calib)
     cfg = {"MODEL": {"EXTRA": synth.W32_EXTRA, "NUM_JOINTS": 17, "TARGET_TYPE": "gaussian"}}
@@ -534,7 +534,8 @@ def test_train_step_with_more_tiles_than_bn_partial_rows(golden_dir, n, h, w):
     x = x + 0.02 * torch.randn(x.shape, generator=torch.Generator().manual_seed(5)).cuda()
     tg = torch.from_numpy(synth.synth_heatmaps(n, 17, h // 4, w // 4, seed=52)).cuda()
     tw = torch.ones(n, 17, 1, device="cuda")
-    assert (h // 2 // (2 if w == 192 else 1)) * n > _lib.lib().udp_bn_rows_max() or n * 128 > _lib.lib().udp_bn_rows_max()
+    # stem conv1 tiles (conv_choose_tile): two column tiles per row band, bands of 2 rows at 96 columns / 1 row at 128
+    assert (h // 2) * 2 * n // (2 if w == 192 else 1) > _lib.lib().udp_bn_rows_max()
     out = {}
     for fused in (True, False):
         tr = HRNetTrainer(cfg, sd0, device="cuda", lr=1e-3)
@@ -543,8 +544,12 @@ def test_train_step_with_more_tiles_than_bn_partial_rows(golden_dir, n, h, w):
         out[fused] = (loss, tr.flat.clone())
         assert np.isfinite(loss).all() and torch.isfinite(tr.flat).all()
         del tr
-    np.testing.assert_array_equal(out[True][0], out[False][0])
-    assert torch.equal(out[True][1], out[False][1])
+    # Only the stem convs fall back; every other layer keeps its per-tile partial rows, whose fp64 summation order
+    # differs from the separate pass's block partition: statistics agree to ~1e-16, so the fp64 loss to an ulp, and
+    # a parameter can only differ where that ulp flipped an fp32 rounding (Adam's first step is +-lr: at most 2 lr).
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=1e-12, atol=0)
+    diff = (out[True][1] - out[False][1]).abs()
+    assert float((diff > 0).float().mean()) < 1e-3 and float(diff.max()) <= 2.1e-3
 
 
 def test_bf16_storage_training_tracks_fp32_and_learns():
