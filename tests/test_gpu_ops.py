@@ -116,6 +116,10 @@ CONV_CASES = [
     (3, 2, 48, 96, 96, 72, 2, True, True, 1),      # W48 fuse chain end
     (1, 1, 192, 48, 24, 18, 2, False, False, 0),   # W48 fuse 1x1
     (3, 1, 16, 16, 24, 16, 2, True, True, 0),      # width-16 mini net of the reference fixture
+    (3, 1, 32, 32, 64, 48, 5, True, True, 1),      # 3x3 stride 1 with an upsampled addend in the epilogue
+    (3, 1, 64, 64, 32, 24, 7, False, True, 0),     # no ReLU, residual, odd image count
+    (3, 1, 192, 192, 24, 18, 3, True, True, 0),    # W48 branch 2 (6 K chunks, ragged row tiles)
+    (3, 1, 384, 384, 12, 9, 5, True, True, 0),     # W48 branch 3 (12 K chunks, two cout blocks per tile)
 ]
 
 

@@ -27,7 +27,7 @@ struct H2 {};
 #define UDP_WS_AD 3     // A-fragment ring depth of the weight-stationary kernels (4 / 5: 245 / 256 registers, -0.6 / -1.5 %)
 #endif
 #ifndef UDP_WS_DBG
-#define UDP_WS_DBG 0   // ablation bits for diagnostic builds (tools/ablate_ws.sh): 1 no A prefetch, 2 no B reads, 4 no DMA after chunk 0
+#define UDP_WS_DBG 0   // ablation bits for diagnostic builds (tools/ablate_ws.sh): 1 no A prefetch, 2 no B reads, 4 no DMA after chunk 0, 16 one MFMA per block
 #endif
 constexpr float kLoScale = 2048.f, kLoInv = 1.f / 2048.f;
 
@@ -72,6 +72,12 @@ __device__ __forceinline__ void stamp(int k) {
   }
 }
 #define UDP_STAMP(k) stamp(k)
+// a value (not a time) into stamp slot k of the wave's record
+__device__ __forceinline__ void stamp_val(int k, unsigned long long v) {
+  if ((threadIdx.x & 63) == 0 && g_stamps)
+    g_stamps[((size_t)(blockIdx.x + gridDim.x * blockIdx.y) * 4 + (threadIdx.x >> 6)) * 16 + k] = v;
+}
+#define UDP_STAMP_VAL(k, v) stamp_val(k, v)
 #ifdef UDP_STAMPS_WS_ONLY          // tools/stamp_multi.py: only the weight-stationary kernels leave stamps
 #define UDP_STAMP_MFMA(k)
 #else
@@ -79,6 +85,7 @@ __device__ __forceinline__ void stamp(int k) {
 #endif
 #else
 #define UDP_STAMP(k)
+#define UDP_STAMP_VAL(k, v)
 #define UDP_STAMP_MFMA(k)
 #endif
 

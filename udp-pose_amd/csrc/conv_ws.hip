@@ -264,12 +264,16 @@ __device__ __forceinline__ void conv_ws_body(const ConvParams& p, const int tile
       if (i + 2 < PB) load_b(i + 2, xh[(i + 2) % 3], xl[(i + 2) % 3]);
 #endif
       __builtin_amdgcn_sched_barrier(0);   // keep those LDS reads ahead of this block's MFMAs (hipcc sinks them otherwise)
+#if UDP_WS_DBG & 16      // (timing-only build: one MFMA instead of six per block, everything else in place)
+      acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[BUF][0] + al[BUF][1] + a2[0] + a2[1], xh[i % 3] + xl[i % 3], acc[i][0], 0, 0, 0);
+#else
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[BUF][nb], xh[i % 3], acc[i][nb], 0, 0, 0);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[BUF][nb], xh[i % 3], acc[i][nb], 0, 0, 0);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[nb], xl[i % 3], acc[i][nb], 0, 0, 0);
+#endif
     }
     if (++tap == TAPS) {
       tap = 0;
