@@ -14,14 +14,16 @@ ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--warmup", type=int, default=2)
 ap.add_argument("--dtype", default="f32")
 ap.add_argument("--target", default="gaussian")
+ap.add_argument("--backend", default="nccl")
 ap.add_argument("--no-graph", action="store_true", help="one ctypes launch per kernel instead of replaying the captured step")
 a = ap.parse_args()
 # one process per GPU under torch.distributed.run (backend nccl = RCCL); plain `python` = one GPU
 world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
 if world > 1:
     import torch.distributed as dist
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-    dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) if a.backend == "nccl" else 0)
+    # --backend gloo: several ranks on ONE GPU (the one-GPU test box); RCCL needs a device per rank
+    dist.init_process_group(a.backend, rank=rank, world_size=world)
 nj = 17
 sd = synth.synth_state_dict(synth.W32_EXTRA, nj, a.target, seed=0)
 tr = HRNetTrainer({"MODEL": {"EXTRA": synth.W32_EXTRA, "NUM_JOINTS": nj, "TARGET_TYPE": a.target}}, sd, dtype=a.dtype)
@@ -29,11 +31,11 @@ x = torch.from_numpy(synth.synth_crops(a.batch, 256, 192, seed=1 + rank)).cuda()
 c = nj * (3 if a.target == "offset" else 1)
 tg = torch.from_numpy(synth.synth_heatmaps(a.batch, nj, 64, 48, seed=2, channels_per_joint=c // nj)).cuda()
 tw = torch.ones(a.batch, nj, 1, device="cuda")
-graphed = world == 1 and not a.no_graph          # the exchange step of N > 1 runs on torch.distributed's stream: eager
+graphed = not a.no_graph          # N > 1: graph segments between the gradient buckets' all-reduces (train.py)
 
 
 def step():
-    return tr.train_step_graphed(x, tg, tw) if graphed else tr.train_step(x, tg, tw, world_size=world)
+    return tr.train_step_graphed(x, tg, tw, world_size=world) if graphed else tr.train_step(x, tg, tw, world_size=world)
 
 
 for _ in range(max(a.warmup, 2 if graphed else 0)):

@@ -173,8 +173,10 @@ def train(config, train_loader, model, criterion, optimizer, epoch=0, output_dir
         tw = target_weight.to(trainer.device, non_blocking=True) if use_tw else \
             torch.ones(n, trainer.num_joints, 1, dtype=torch.float32, device=trainer.device)
         x, tg = input.to(trainer.device, non_blocking=True).contiguous(), target.to(trainer.device, non_blocking=True)
-        if world_size == 1 and os.environ.get("UDP_POSE_NO_TRAIN_GRAPH") is None:
-            loss = trainer.train_step_graphed(x, tg, tw)             # the step replayed as a hipGraph (same results)
+        if os.environ.get("UDP_POSE_NO_TRAIN_GRAPH") is None:
+            # the step replayed as hipGraph(s) (same results); N > 1: in segments between the gradient buckets'
+            # all-reduces, which the host issues while the next segment runs
+            loss = trainer.train_step_graphed(x, tg, tw, world_size=world_size)
         else:
             loss = trainer.train_step(x, tg, tw, world_size=world_size)
         if not isinstance(model, HRNetTrainer):

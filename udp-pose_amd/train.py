@@ -584,41 +584,60 @@ class HRNetTrainer:
         self._out = self._conv(ys[0], "final_layer", bias_key="final_layer.bias", nchw_out=True)
         return self._out.buf
 
-    def backward(self, dheat, world_size=1):
-        """dheat: fp32 [N,C,h,w] = d loss / d heat-maps.  Fills self.grad (zero_grad is implicit: every
-        parameter gradient is overwritten).  ``world_size > 1``: every gradient bucket is SUM-all-reduced
-        (asynchronously, on the communication stream of torch.distributed) as soon as its last gradient has been
-        written, overlapping the rest of the backward; on return all buckets are reduced."""
+    def _backward_walk(self, dheat, pre=None):
+        """The tape in reverse.  Yields the list of gradient buckets a backward node has just completed (the node wrote
+        their last gradient), and finally the buckets no node completed (a bucket with an unused parameter: its gradient
+        stays as is).  ``pre()`` is called before anything is launched after a yield (segmented graph capture opens its
+        next segment there).  Every parameter gradient is overwritten (implicit zero_grad)."""
         L = _lib.lib()
+        if pre:
+            pre()
         o = self._out
         g = torch.empty(o.n * o.h * o.w * o.ck, dtype=self._tdt, device=self.device)
         _lib.check(L.udp_nchw_to_nhwc(dheat.data_ptr(), o.n, o.c, o.h, o.w, o.ck, g.data_ptr(), self._dt, self._stream()))
         o.grad = g
         left = [c for _, _, c in self._buckets]
+        for y, bwd, _, keys in reversed(self._tape):
+            done = []
+            if y.grad is not None:
+                if pre:
+                    pre()
+                bwd()
+                for k in keys:
+                    b = self._bucket_of[k]
+                    left[b] -= 1
+                    if left[b] == 0:
+                        done.append(b)
+            y.grad = None
+            if done:
+                yield done
+        self._tape = []
+        rest = [b for b, n_left in enumerate(left) if n_left > 0]
+        if rest:
+            yield rest
+
+    def backward(self, dheat, world_size=1):
+        """dheat: fp32 [N,C,h,w] = d loss / d heat-maps.  Fills self.grad (zero_grad is implicit: every
+        parameter gradient is overwritten).  ``world_size > 1``: every gradient bucket is SUM-all-reduced
+        (asynchronously, on the communication stream of torch.distributed) as soon as its last gradient has been
+        written, overlapping the rest of the backward; on return all buckets are reduced."""
         works = []
         self.reduce_order = []                # bucket indices in the order their all-reduce was issued
-        for y, bwd, _, keys in reversed(self._tape):
-            if y.grad is not None:
-                bwd()
-                if world_size > 1:
-                    for k in keys:
-                        b = self._bucket_of[k]
-                        left[b] -= 1
-                        if left[b] == 0:
-                            works.append(self._reduce_bucket(b))
-            y.grad = None
-        self._tape = []
-        if world_size > 1:
-            for b, n_left in enumerate(left):          # a bucket with an unused parameter: its gradient stays as is
-                if n_left > 0:
-                    works.append(self._reduce_bucket(b))
-            for w in works:
-                w.wait()
+        for done in self._backward_walk(dheat):
+            if world_size > 1:
+                works += [self._reduce_bucket(b) for b in done]
+        for w in works:
+            w.wait()
 
     def _reduce_bucket(self, b):
         from .dist import allreduce_sum_async
         lo, hi, _ = self._buckets[b]
         self.reduce_order.append(b)
+        if os.environ.get("UDP_POSE_FAKE_ALLREDUCE"):        # timing diagnosis only (tools/bench_train.py): no exchange
+            class _Done:
+                def wait(self):
+                    return True
+            return _Done()
         return allreduce_sum_async(self.grad[lo:hi])
 
     def loss_and_grad(self, heat, target, target_weight):
@@ -643,26 +662,36 @@ class HRNetTrainer:
                                             self.betas[1], self.eps, self.step_count, float(grad_scale),
                                             self._stream()))
 
-    def _adam_step_dev(self):
+    def _adam_step_dev(self, grad_scale=1.0):
         _lib.check(_lib.lib().udp_adam_step_dev(self.flat.data_ptr(), self.grad.data_ptr(), self.exp_avg.data_ptr(),
                                                 self.exp_avg_sq.data_ptr(), self._n_param, self.betas[0], self.betas[1],
-                                                self.eps, self._coef.data_ptr(), 1.0, self._stream()))
+                                                self.eps, self._coef.data_ptr(), float(grad_scale), self._stream()))
 
-    def train_step_graphed(self, x, target, target_weight):
-        """train_step for one GPU with the whole step (weight packing, forward, criterion, backward, Adam: ~1900
+    def train_step_graphed(self, x, target, target_weight, world_size=1):
+        """train_step with the whole step (weight packing, forward, criterion, backward, Adam: ~1900
         launches issued from the Python tape) captured ONCE per input shape as a hipGraph (torch.cuda.graph: stream
         capture of our launches on torch's capture stream, activations from the graph's private pool) and replayed:
         the host then costs one graph launch per step instead of one ctypes call per kernel.  The first step of a
         shape runs eagerly (lazy one-time initialisation must not be captured), the second captures and replays.
         Arithmetic and results are those of train_step, bit for bit; the learning rate may change between steps
         (it only enters through Adam's two scalars, uploaded before every replay), betas / eps are part of the key.
-        At most two shapes stay captured (a full and a ragged last batch)."""
-        key = (tuple(x.shape), tuple(target.shape), tuple(target_weight.shape), self.betas, self.eps)
+        At most two shapes stay captured (a full and a ragged last batch).
+
+        ``world_size > 1`` (one process per GPU, config 3): the step is captured in SEGMENTS that end where a gradient
+        bucket receives its last gradient -- forward + criterion + the backward of the last layers; the backward
+        between two bucket boundaries; ...; and Adam on its own.  A replayed step is: replay segment 0, issue the
+        asynchronous SUM all-reduce of its bucket(s) from the host (torch.distributed orders it behind the segment on
+        its communication stream: RCCL over xGMI, or gloo), replay segment 1 at once -- the exchange runs under it, as
+        DistributedDataParallel's reducer overlaps the reference's backward -- and so on; the work handles are waited
+        for (stream order, no host block under RCCL) before the Adam graph with grad_scale 1 / world_size.  All
+        segments share one memory pool and are always replayed in capture order.  Same arithmetic, same bucket order
+        and the same results as train_step(world_size), bit for bit."""
+        key = (tuple(x.shape), tuple(target.shape), tuple(target_weight.shape), self.betas, self.eps, int(world_size))
         ent = self._graphs.get(key)
         if ent is None:
             if key not in self._warm:                                # first step of this shape: eager
                 self._warm.add(key)
-                return self.train_step(x, target, target_weight)
+                return self.train_step(x, target, target_weight, world_size=world_size)
             if self._coef is None:
                 self._coef = torch.zeros(2, dtype=torch.float32, device=self.device)
                 # pinned staging slots for the asynchronous upload of Adam's two scalars: the host runs steps ahead
@@ -673,14 +702,18 @@ class HRNetTrainer:
             torch.cuda.synchronize()             # the last replay of an evicted graph may still be running
             while len(self._graphs) >= 2:
                 self._graphs.pop(next(iter(self._graphs)))
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                heat = self.forward(gx)
-                self.loss_and_grad(heat, gt, gw)
-                self.backward(self._loss_grad)
-                self._adam_step_dev()
-            ent = self._graphs[key] = (graph, gx, gt, gw)
-        graph, gx, gt, gw = ent
+            if world_size == 1:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    heat = self.forward(gx)
+                    self.loss_and_grad(heat, gt, gw)
+                    self.backward(self._loss_grad)
+                    self._adam_step_dev()
+                segs = [(graph, [])]
+            else:
+                segs = self._capture_segments(gx, gt, gw, 1.0 / world_size)
+            ent = self._graphs[key] = (segs, gx, gt, gw)
+        segs, gx, gt, gw = ent
         gx.copy_(x, non_blocking=True)
         gt.copy_(target, non_blocking=True)
         gw.copy_(target_weight, non_blocking=True)
@@ -693,9 +726,57 @@ class HRNetTrainer:
         self._coef.copy_(self._coef_host[slot], non_blocking=True)
         self._coef_done[slot] = torch.cuda.Event()
         self._coef_done[slot].record()
-        graph.replay()
+        works = []
+        self.reduce_order = []
+        for graph, buckets in segs:
+            if graph is None:                                        # every bucket is reduced: Adam may read the gradient
+                for w in works:
+                    w.wait()
+                continue
+            graph.replay()
+            works += [self._reduce_bucket(b) for b in buckets]
         self.version += 1
         return self._loss
+
+    def _capture_segments(self, gx, gt, gw, grad_scale):
+        """The step as a list of (graph, buckets to all-reduce after it) in replay order, a (None, []) marker where
+        the outstanding all-reduces must be waited for, and the Adam graph last."""
+        pool = torch.cuda.graph_pool_handle()
+        segs = []
+        cur = []                                    # [graph, context] of the segment being captured, or empty
+
+        def begin():
+            if not cur:
+                g = torch.cuda.CUDAGraph()
+                ctx = torch.cuda.graph(g, pool=pool)
+                ctx.__enter__()
+                cur[:] = [g, ctx]
+
+        def end(buckets):
+            if cur:
+                cur[1].__exit__(None, None, None)
+                segs.append((cur[0], list(buckets)))
+                cur[:] = []
+            elif buckets:                           # buckets nothing was launched for since the last boundary
+                segs[-1] = (segs[-1][0], segs[-1][1] + list(buckets))
+
+        try:
+            begin()
+            heat = self.forward(gx)
+            self.loss_and_grad(heat, gt, gw)
+            for done in self._backward_walk(self._loss_grad, pre=begin):
+                end(done)
+            end([])                                 # nodes behind the last bucket boundary (they write no parameter gradient)
+        except BaseException:
+            if cur:
+                cur[1].__exit__(None, None, None)
+            raise
+        segs.append((None, []))
+        adam = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(adam, pool=pool):
+            self._adam_step_dev(grad_scale)
+        segs.append((adam, []))
+        return segs
 
     def train_step(self, x, target, target_weight, world_size=1):
         """function.py:46-76 for one batch.  Returns the loss tensor fp64 [2] = (L_hm, L_offset) on device."""
