@@ -6,12 +6,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 
+DT = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+
+
 def run(total, k, steps=30, warmup=5):
     dev = torch.device("cuda", 0)
-    sd, _ = bench.build_net("bf16")
     hps, streams = [], []
     for i in range(k):
-        _, net = bench.build_net("bf16")
+        _, net = bench.build_net(DT)
         s = torch.cuda.Stream()
         with torch.cuda.stream(s):
             hps.append(bench.HotPath(net, total // k, dev, seed=1 + i))
@@ -30,5 +32,5 @@ def run(total, k, steps=30, warmup=5):
     dt = (time.time() - t0) / steps
     print("batch %d as %d stream(s): %.3f ms/step, %.0f img/s" % (total, k, dt * 1e3, total / dt), flush=True)
 
-for total, k in ((64, 1), (64, 2), (64, 4), (128, 2)):
+for total, k in ((64, 1), (64, 2), (128, 2), (192, 3), (256, 4), (128, 1)):
     run(total, k)

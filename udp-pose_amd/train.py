@@ -131,6 +131,10 @@ class HRNetTrainer:
         self._graphs, self._warm, self._coef = {}, set(), None            # train_step_graphed
         self.version = 0                      # bumped by every optimizer step (the owning model's staleness check)
         self._tape = []
+        # weight gradients on a side stream beside the backward chain (_on_side); A/B knob UDP_POSE_NO_WGRAD_OVERLAP
+        self.overlap_wgrad = os.environ.get("UDP_POSE_NO_WGRAD_OVERLAP") is None and torch.device(self.device).type == "cuda"
+        self._side = torch.cuda.Stream(device=self.device) if self.overlap_wgrad else None
+        self._side_keep, self._side_busy = [], False
         self.fuse_bn_stats = os.environ.get("UDP_POSE_NO_BN_FUSION") is None     # A/B knob
         # gradient buckets for the all-reduce (~25 MB each): consecutive parameters of the flat
         # gradient; a bucket is reduced as soon as the backward has written its last gradient, so the exchange
@@ -177,6 +181,27 @@ class HRNetTrainer:
     # ------------------------------------------------------------------ primitive ops
     def _stream(self):
         return _lib.stream_ptr()
+
+    def _on_side(self, fn, *keep):
+        """Run the launches of ``fn`` on the side stream, ordered behind everything queued on the current stream so far
+        (fork).  The weight gradients go there: nothing in the backward chain reads them -- only the bucket all-reduce /
+        Adam, behind ``_join_side`` -- and at 32 images per GPU the chain's kernels (48-1024 workgroups, BatchNorm
+        passes) leave most of the chip idle.  ``keep``: tensors the side launches read; they stay referenced until the
+        join, so the allocator cannot hand their memory to the main stream's next kernels."""
+        if not self.overlap_wgrad:
+            fn()
+            return
+        self._side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._side):
+            fn()
+        self._side_keep.extend(keep)
+        self._side_busy = True
+
+    def _join_side(self):
+        if self._side_busy:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._side_keep.clear()
+            self._side_busy = False
 
     def _new(self, n, h, w, c, needs_grad=True):
         ck = _rup(c, 16)
@@ -236,12 +261,15 @@ class HRNetTrainer:
 
         def backward():
             dy = y.grad                                   # NHWC [n,ho,wo,ck(cout)]
-            _lib.check(L.udp_conv2d_wgrad(x.buf.data_ptr(), dy.data_ptr(), x.n, x.h, x.w, x.ck, ho, wo, y.ck, ks,
-                                          stride, cout, cin, self._dt, self._g(name + ".weight"), 0,
-                                          self._wgrad_ws.data_ptr(), self._wgrad_ws.numel(), self._stream()))
-            if bias_key:
-                _lib.check(L.udp_bias_grad(dy.data_ptr(), x.n * ho * wo, y.ck, cout, self._g(bias_key), self._dt,
-                                           self._stream()))
+
+            def wgrad():
+                _lib.check(L.udp_conv2d_wgrad(x.buf.data_ptr(), dy.data_ptr(), x.n, x.h, x.w, x.ck, ho, wo, y.ck, ks,
+                                              stride, cout, cin, self._dt, self._g(name + ".weight"), 0,
+                                              self._wgrad_ws.data_ptr(), self._wgrad_ws.numel(), self._stream()))
+                if bias_key:
+                    _lib.check(L.udp_bias_grad(dy.data_ptr(), x.n * ho * wo, y.ck, cout, self._g(bias_key), self._dt,
+                                               self._stream()))
+            self._on_side(wgrad, dy, x.buf)
             if not x.needs_grad:
                 return
             src, hh, ww = dy, ho, wo
@@ -394,7 +422,8 @@ class HRNetTrainer:
                 w.workspace, w.workspace_bytes = self._wgrad_wss[slot].data_ptr(), self._wgrad_wss[slot].numel()
                 w.n, w.hin, w.win, w.cin_k, w.hout, w.wout, w.cout_k = x.n, x.h, x.w, x.ck, x.h, x.w, y.ck
                 w.ks, w.stride, w.cout, w.cin, w.accumulate = ks, 1, cout, cin, 0
-            _lib.check(L.udp_conv2d_wgrad_group(wi, nb, self._dt, self._stream()))
+            self._on_side(lambda: _lib.check(L.udp_conv2d_wgrad_group(wi, nb, self._dt, self._stream())),
+                          *[xs[b].buf for b in order], *[ys[b].grad for b in order])
             for b in order:
                 x, y, (cout, cin, ks, wf, wd) = xs[b], ys[b], metas[b]
                 if not x.needs_grad:
@@ -610,8 +639,10 @@ class HRNetTrainer:
                         done.append(b)
             y.grad = None
             if done:
+                self._join_side()             # the bucket's weight gradients were written on the side stream
                 yield done
         self._tape = []
+        self._join_side()
         rest = [b for b, n_left in enumerate(left) if n_left > 0]
         if rest:
             yield rest
