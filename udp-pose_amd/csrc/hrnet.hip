@@ -49,6 +49,9 @@ struct udp_hrnet {
   std::vector<hipEvent_t> op_done;     // one per op (recorded only where another lane waits on it)
   std::vector<char> op_signals;        // op has a cross-lane consumer
   hipEvent_t ev_fork = nullptr, ev_join[UDP_MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+  // sub-batch lanes (udp_hrnet_forward): the second half of a batch runs on this stream beside the first
+  hipStream_t split_stream = nullptr;
+  hipEvent_t split_fork = nullptr, split_join = nullptr;
 };
 
 static size_t esize(int dtype) { return dtype == UDP_BF16 ? 2 : 4; }   // bytes per stored element (F16X2: hi + lo)
@@ -231,9 +234,34 @@ extern "C" int udp_hrnet_create(const udp_conv_op* ops, int n_ops, const int64_t
   return UDP_OK;
 }
 
+static size_t ws_bytes_one(const udp_hrnet* h, int n, int flip) {
+  const size_t b = (size_t)h->total_elems * (size_t)(n * (flip ? 2 : 1)) * esize(h->dtype);
+  return (b + 255) & ~(size_t)255;
+}
+static size_t out_bytes(const udp_hrnet* h, int images) {
+  return (size_t)images * h->out_channels * (size_t)(h->in_h / 4) * (size_t)(h->in_w / 4) * sizeof(float);
+}
+// Sub-batch lanes: a batch of the split-fp16 mode is run as two halves, each its own hipGraph, the second on an
+// internal stream BESIDE the first (fork / join by events on the caller's stream).  Measured with two independent
+// graph replays on two streams (tools/dual_stream.py, 64 crops + mirrored copies): W32 256x192 7.39 -> 7.81-7.92 k
+// images/s, RSN-18 9.67 -> 10.93 k, W48 384x288 1.55 -> 1.53 k; four lanes: 4.5 k.  The launches of one chain leave
+// the chip idle between a kernel's last workgroups and its successor's first HBM round trip (42 % of the workgroup
+// slot time of the dominant launch is outside its MFMA loop, NOTES.md); a second, independent chain fills those gaps.
+// Images are independent (same result for an image whatever batch it arrives in -- tests/test_gpu_e2e.py), so the
+// split changes no number.  Default: split-fp16 mode, inputs up to 256x192, 16 crops or more; UDP_POSE_LANES=1 / 2
+// forces it off / on.
+static bool split_ok(const udp_hrnet* h, int n) {
+  if (h->dtype != UDP_F16X2 || n < 16) return false;
+  const char* e = getenv("UDP_POSE_LANES");
+  if (e) return atoi(e) >= 2;
+  return (long)h->in_h * h->in_w <= 256L * 192L;
+}
 extern "C" size_t udp_hrnet_workspace_bytes(const udp_hrnet* h, int n, int flip_test) {
   if (!h || n <= 0) return 0;
-  return (size_t)h->total_elems * (size_t)(n * (flip_test ? 2 : 1)) * esize(h->dtype);
+  if (!split_ok(h, n)) return ws_bytes_one(h, n, flip_test);
+  const int n0 = (n + 1) / 2;
+  // two lanes' workspaces + (flip test) their [normal | mirrored] heat-maps before they are copied into place
+  return ws_bytes_one(h, n0, flip_test) + ws_bytes_one(h, n - n0, flip_test) + (flip_test ? out_bytes(h, 2 * n) + 512 : 0);
 }
 
 extern "C" int udp_hrnet_num_launches(const udp_hrnet* h) { return h ? (int)h->ops.size() : 0; }
@@ -493,12 +521,9 @@ extern "C" int udp_hrnet_profile(udp_hrnet* h, const float* in_nchw, int n, int 
   return UDP_OK;
 }
 
-extern "C" int udp_hrnet_forward(udp_hrnet* h, const float* in_nchw, int n, int flip_test, void* workspace,
-                                 size_t workspace_bytes, float* heatmaps_nchw, int use_graph, void* stream) {
-  int rc = check_forward_args("udp_hrnet_forward", h, in_nchw, n, flip_test, workspace, workspace_bytes, heatmaps_nchw);
-  if (rc) return rc;
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  flip_test = flip_test ? 1 : 0;
+static int forward_one(udp_hrnet* h, const float* in_nchw, int n, int flip_test, void* workspace, float* heatmaps_nchw,
+                       int use_graph, hipStream_t s) {
+  int rc;
   if (use_graph)
     for (size_t k = 0; k < h->graphs.size(); ++k) {
       const GraphEntry g = h->graphs[k];
@@ -525,9 +550,9 @@ extern "C" int udp_hrnet_forward(udp_hrnet* h, const float* in_nchw, int n, int 
   rc = build_graph(h, L, &e.graph, &e.exec);
   if (rc) return rc;
   if (h->graphs.size() >= 8) {
-    // evict the least recently used graph; its last replay may still be running on the (single) stream of
-    // this handle -> drain the stream before the executable goes away
-    UDP_HIP_CHECK(hipStreamSynchronize(s));
+    // evict the least recently used graph; its last replay may still be running (on the caller's stream or on the
+    // second lane's) -> drain the device before the executable goes away
+    UDP_HIP_CHECK(hipDeviceSynchronize());
     (void)hipGraphExecDestroy(h->graphs[0].exec);
     (void)hipGraphDestroy(h->graphs[0].graph);
     h->graphs.erase(h->graphs.begin());
@@ -537,8 +562,59 @@ extern "C" int udp_hrnet_forward(udp_hrnet* h, const float* in_nchw, int n, int 
   return UDP_OK;
 }
 
+extern "C" int udp_hrnet_forward(udp_hrnet* h, const float* in_nchw, int n, int flip_test, void* workspace,
+                                 size_t workspace_bytes, float* heatmaps_nchw, int use_graph, void* stream) {
+  int rc = check_forward_args("udp_hrnet_forward", h, in_nchw, n, flip_test, workspace, workspace_bytes, heatmaps_nchw);
+  if (rc) return rc;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  flip_test = flip_test ? 1 : 0;
+  if (!use_graph || !split_ok(h, n)) return forward_one(h, in_nchw, n, flip_test, workspace, heatmaps_nchw, use_graph, s);
+  // ---- two sub-batch lanes
+  if (!h->split_stream) {
+    UDP_HIP_CHECK(hipStreamCreateWithFlags(&h->split_stream, hipStreamNonBlocking));
+    UDP_HIP_CHECK(hipEventCreateWithFlags(&h->split_fork, hipEventDisableTiming));
+    UDP_HIP_CHECK(hipEventCreateWithFlags(&h->split_join, hipEventDisableTiming));
+  }
+  const int n0 = (n + 1) / 2, n1 = n - n0;
+  char* ws0 = reinterpret_cast<char*>(workspace);
+  char* ws1 = ws0 + ws_bytes_one(h, n0, flip_test);
+  const size_t img_in = (size_t)3 * h->in_h * h->in_w;
+  const size_t img_out = out_bytes(h, 1) / sizeof(float);
+  hipStream_t s2 = h->split_stream;
+  UDP_HIP_CHECK(hipEventRecord(h->split_fork, s));
+  UDP_HIP_CHECK(hipStreamWaitEvent(s2, h->split_fork, 0));
+  if (!flip_test) {
+    rc = forward_one(h, in_nchw, n0, 0, ws0, heatmaps_nchw, 1, s);
+    if (!rc) rc = forward_one(h, in_nchw + n0 * img_in, n1, 0, ws1, heatmaps_nchw + n0 * img_out, 1, s2);
+  } else {
+    // a lane's heat-maps are [its images | their mirrored copies]; the caller's layout is [all images | all mirrored]
+    float* t0 = reinterpret_cast<float*>(ws1 + ws_bytes_one(h, n1, 1));
+    float* t1 = t0 + 2 * n0 * img_out;
+    rc = forward_one(h, in_nchw, n0, 1, ws0, t0, 1, s);
+    if (!rc) {
+      UDP_HIP_CHECK(hipMemcpyAsync(heatmaps_nchw, t0, n0 * img_out * sizeof(float), hipMemcpyDeviceToDevice, s));
+      UDP_HIP_CHECK(hipMemcpyAsync(heatmaps_nchw + n * img_out, t0 + n0 * img_out, n0 * img_out * sizeof(float), hipMemcpyDeviceToDevice, s));
+      rc = forward_one(h, in_nchw + n0 * img_in, n1, 1, ws1, t1, 1, s2);
+    }
+    if (!rc) {
+      UDP_HIP_CHECK(hipMemcpyAsync(heatmaps_nchw + n0 * img_out, t1, n1 * img_out * sizeof(float), hipMemcpyDeviceToDevice, s2));
+      UDP_HIP_CHECK(hipMemcpyAsync(heatmaps_nchw + (n + n0) * img_out, t1 + n1 * img_out, n1 * img_out * sizeof(float), hipMemcpyDeviceToDevice, s2));
+    }
+  }
+  // join (also after an error in a lane: whatever was enqueued on the second stream is ordered before the caller's next work)
+  UDP_HIP_CHECK(hipEventRecord(h->split_join, s2));
+  UDP_HIP_CHECK(hipStreamWaitEvent(s, h->split_join, 0));
+  return rc;
+}
+
 extern "C" int udp_hrnet_destroy(udp_hrnet* h) {
   if (!h) return UDP_OK;
+  if (h->split_stream) {
+    (void)hipStreamSynchronize(h->split_stream);
+    (void)hipStreamDestroy(h->split_stream);
+    (void)hipEventDestroy(h->split_fork);
+    (void)hipEventDestroy(h->split_join);
+  }
   for (auto& g : h->graphs) {
     (void)hipGraphExecDestroy(g.exec);
     (void)hipGraphDestroy(g.graph);
