@@ -17,6 +17,8 @@ does NOT meet the contract and is never the headline.
 
 With --gpus N > 1 and no torch.distributed environment the script starts N ranks of itself
 (python -m torch.distributed.run, one per GPU) before anything touches the GPU and relays rank 0's line.
+A batch of the split-fp16 mode runs as two sub-batch lanes inside udp_hrnet_forward (two hipGraphs on two streams, joined
+before the flip fuse; include/udp_pose_hip.h: udp_hrnet_lanes) -- still one step = one batch of 64 crops.
 Prints ONE JSON line (rank 0).  `value` is whole-job images/s; multi-GPU is weak scaling over
 independent replicas (every rank decodes its own batch; no data-path collective).  The line also
 carries `roofline` (dominant kernel class: algorithmic FLOPs / measured launch time vs the dense
@@ -141,6 +143,8 @@ def roofline(net, hp, steps, dtype):
         classes[key][3] = len(ids)
     dom = max(classes, key=lambda k: classes[k][0])
     t_ms, flops, byts, cnt = classes[dom]
+    handle = net._compiled[(hp.h, hp.w)][0]
+    lanes = int(_lib.lib().udp_hrnet_lanes(handle, hp.n)) if net.use_graph else 1
     achieved = flops / (t_ms * 1e-3) / 1e12
     table = {k: {"ms": round(v[0], 4), "launches": v[3], "tflops": round(v[1] / (v[0] * 1e-3) / 1e12, 2) if v[0] > 0 else 0,
                  "gbs": round(v[2] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else 0} for k, v in classes.items()}
@@ -179,6 +183,11 @@ def roofline(net, hp, steps, dtype):
             "peak": round(PEAK_TFLOPS[dtype], 1), "unit": "TFLOP/s", "frac": round(achieved / PEAK_TFLOPS[dtype], 4),
             "peak_note": {"f16x2": "algorithmic FLOP/s against the dense fp16 MFMA peak (2.5 PF) / 3 MFMAs per product",
                           "bf16": "dense bf16 MFMA peak", "f32": "fp32 MFMA peak"}[dtype],
+            "lanes_in_timed_region": lanes,
+            "measured_as": ("instrumented eager pass of the whole batch in ONE lane (the kernel alone on the chip; rocprofv3 of "
+                            "`UDP_POSE_LANES=1 bench.py` agrees); the timed region runs the batch as two half-batch lanes whose "
+                            "launches overlap -- see whole_step for what that adds") if lanes > 1 else
+                           "instrumented eager pass of the launches of the timed region",
             "traffic": traffic, "traffic_source": os.path.basename(tfile) if traffic else None,
             "launches_per_step": cnt, "avg_launch_us": round(t_ms / cnt * 1e3, 2),
             "algorithmic_gflop_per_launch": round(flops / cnt / 1e9, 3),

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libudp_pose_hip.so does not export %s" % name
     assert declared == set(_lib.EXPORTS)
-    assert lib.udp_abi_version() == _lib.ABI_VERSION == 16
+    assert lib.udp_abi_version() == _lib.ABI_VERSION == 17
 
 
 def test_argument_validation_without_gpu():

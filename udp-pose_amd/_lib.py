@@ -16,7 +16,7 @@ DTYPES = {"f32": UDP_F32, "bf16": UDP_BF16, "f16x2": UDP_F16X2}
 UDP_OP_STEM, UDP_OP_CONV, UDP_OP_FUSE, UDP_OP_STEM7, UDP_OP_MAXPOOL, UDP_OP_BILINEAR = 0, 1, 2, 3, 4, 5
 UDP_OP_PSA_POOL, UDP_OP_PSA_MLP, UDP_OP_PSA_SCALE, UDP_OP_PSA_SP, UDP_OP_BLOCK = 6, 7, 8, 9, 10
 UDP_BUF_NONE, UDP_BUF_OUTPUT = -1, -2
-ABI_VERSION = 16
+ABI_VERSION = 17
 MAX_LANES, MAX_WAIT = 4, 8
 
 
@@ -82,6 +82,7 @@ _SIGS = {
     "udp_hrnet_profile": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_size_t, _P, C.POINTER(C.c_float), _P]),
     "udp_hrnet_destroy": (C.c_int, [_P]),
     "udp_hrnet_num_launches": (C.c_int, [_P]),
+    "udp_hrnet_lanes": (C.c_int, [_P, C.c_int]),
     "udp_hrnet_flops_per_image": (C.c_double, [_P]),
     "udp_conv2d_fused": (C.c_int, [C.POINTER(ConvOp), C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "udp_conv2d_fused_bn": (C.c_int, [C.POINTER(ConvOp), C.c_int, C.c_int, _P, _P, _P, _P, _P, C.c_size_t,

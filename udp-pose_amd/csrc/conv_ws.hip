@@ -502,6 +502,9 @@ static bool ws_tile(const ConvParams& p, int ks, int stride, int cp, int pb, WsT
   return have;
 }
 
+static long g_ws_fill_wgs = 512;
+void ws_set_fill_wgs(long wgs) { g_ws_fill_wgs = wgs; }
+
 int describe_conv_ws(ConvParams p, int ks, int stride, Launch* out, bool grouped) {
   if ((stride != 1 && stride != 2) || (ks != 3 && ks != 1) || p.out_nchw_f32)
     return fail(UDP_ERR_UNSUPPORTED, "fragment-major weights (wfmt 1): conv ks=%d stride=%d nchw_out=%d has no weight-stationary kernel",
@@ -512,8 +515,10 @@ int describe_conv_ws(ConvParams p, int ks, int stride, Launch* out, bool grouped
   };
   const int pairs = p.CoutPad / 32;
   const int force_cp = (int)knob("UDP_POSE_WS_CP", 0), force_pb = (int)knob("UDP_POSE_WS_PB", 0);
-  // two workgroups on each of the 256 CUs; a member of a merged launch fills the chip with its siblings
-  const long min_wgs = grouped ? 0 : knob("UDP_POSE_WS_MINWGS", 512);
+  // two workgroups on each of the 256 CUs; a member of a merged launch fills the chip with its siblings, and a conv of
+  // a sub-batch lane (hrnet.hip: the other lane's kernels run beside it) is better off with the fatter tile from a
+  // quarter of that on: W32 7.81 -> 7.98 k images/s at 128 (64: 7.88, 192: 7.83, same box)
+  const long min_wgs = grouped ? 0 : knob("UDP_POSE_WS_MINWGS", g_ws_fill_wgs);
   // candidates from the fattest wave tile down: the first one that fills the chip wins, else the one with
   // the most workgroups
   WsTile best{}, t{};

@@ -256,6 +256,7 @@ static bool split_ok(const udp_hrnet* h, int n) {
   if (e) return atoi(e) >= 2;
   return (long)h->in_h * h->in_w <= 256L * 192L;
 }
+extern "C" int udp_hrnet_lanes(const udp_hrnet* h, int n) { return h && n > 0 && split_ok(h, n) ? 2 : 1; }
 extern "C" size_t udp_hrnet_workspace_bytes(const udp_hrnet* h, int n, int flip_test) {
   if (!h || n <= 0) return 0;
   if (!split_ok(h, n)) return ws_bytes_one(h, n, flip_test);
@@ -576,6 +577,10 @@ extern "C" int udp_hrnet_forward(udp_hrnet* h, const float* in_nchw, int n, int 
     UDP_HIP_CHECK(hipEventCreateWithFlags(&h->split_join, hipEventDisableTiming));
   }
   const int n0 = (n + 1) / 2, n1 = n - n0;
+  struct FillHint {                        // tile choice of the lanes' graphs (built on their first call only)
+    FillHint() { ws_set_fill_wgs(128); }
+    ~FillHint() { ws_set_fill_wgs(512); }
+  } fill_hint;
   char* ws0 = reinterpret_cast<char*>(workspace);
   char* ws1 = ws0 + ws_bytes_one(h, n0, flip_test);
   const size_t img_in = (size_t)3 * h->in_h * h->in_w;
