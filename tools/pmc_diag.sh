@@ -2,7 +2,7 @@
 # Stall diagnosis of the split-fp16 forward's kernels: separate rocprofv3 --pmc passes (8 SQ slots / 4 TCC slots per pass)
 # of tools/one_forward.py, per-kernel means.  Usage (GPU box, repo root): tools/pmc_diag.sh <out.txt> [kernel substring]
 out=${1:-gpurun_out/pmc_diag.txt}; sub=${2:-conv_ws}
-root=$PWD; cd /tmp && export TMPDIR=/tmp
+root=$PWD; : > "$root/$out.tmp"; cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VMEM_RD SQ_INST_LEVEL_VMEM SQ_INSTS_LDS SQ_INST_LEVEL_LDS SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL" \
            "SQ_WAVES SQ_IFETCH SQ_IFETCH_LEVEL SQ_LDS_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS" \
