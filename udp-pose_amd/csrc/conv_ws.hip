@@ -447,7 +447,6 @@ static int describe_ws_pb(const ConvParams& p, int pb, int cp, size_t lds, Launc
 struct WsTile {
   int cp, pb, G, R, TW, wgs;
   size_t lds;
-  double slots;   // useful pixels / pixel slots over the whole layer (ragged last tiles, masked blocks = waste)
 };
 // Tile of a (cout pairs per workgroup, pixel blocks per wave) candidate; false if it cannot be built.
 static bool ws_tile(const ConvParams& p, int ks, int stride, int cp, int pb, WsTile* t) {
@@ -498,7 +497,6 @@ static bool ws_tile(const ConvParams& p, int ks, int stride, int cp, int pb, WsT
       t->TW = TW;
       t->lds = lds;
       t->wgs = tiles * (p.CoutPad / (cp * 32));
-      t->slots = (double)p.N * p.Hout * p.Wout / ((double)tiles * 16 * pbe * pg);
     }
   }
   return have;
@@ -525,16 +523,12 @@ int describe_conv_ws(ConvParams p, int ks, int stride, Launch* out, bool grouped
   // the most workgroups
   WsTile best{}, t{};
   bool have = false;
-  const bool util_pick = knob("UDP_POSE_WS_UTIL", 0) != 0;
   for (int pb : {6, 4, 3, 2}) {
     for (int cp : {4, 2, 1}) {
       if (pairs % cp || (force_cp && cp != force_cp) || (force_pb && pb != force_pb)) continue;
       if (!ws_tile(p, ks, stride, cp, pb, &t)) continue;
       const bool fills = t.wgs >= min_wgs, best_fills = have && best.wgs >= min_wgs;
-      // ... unless a smaller cout split wastes far fewer MFMA slots at the same block count (12x9 maps of W48: 96-pixel
-      // tiles of 8 rows leave 44 % of the slots of a 9-row image empty, three whole images per 384-pixel tile 16 %)
-      const bool denser = have && util_pick && t.pb == best.pb && t.slots > best.slots + 0.15;
-      if (!have || (!best_fills && (fills || t.wgs > best.wgs)) || denser) {
+      if (!have || (!best_fills && (fills || t.wgs > best.wgs))) {
         best = t;
         have = true;
       }
