@@ -480,6 +480,24 @@ def main():
                                  "contract (see parity_vs_cpu_oracle.bf16); reported for BASELINE.json configs[1] only"}
         del hp_b
 
+    if not args.no_other_modes and args.dtype == "f16x2" and int(_lib.lib().udp_hrnet_lanes(net._compiled[(in_h, in_w)][0], args.batch)) > 1:
+        # the same mode with the sub-batch lanes off: what the two concurrent chains add (and the configuration the
+        # roofline pass below measures)
+        saved = os.environ.get("UDP_POSE_LANES")
+        os.environ["UDP_POSE_LANES"] = "1"
+        try:
+            _, _, hp_1, dt_1 = time_mode(args.dtype, args, device, rank, in_h, in_w, tt, barrier)
+            dt_1 = max_over_ranks(dt_1)
+            other["f16x2_one_lane"] = {"value": round(world * args.batch * args.steps / dt_1, 1), "unit": "images/s",
+                                       "ms_per_step": round(dt_1 / args.steps * 1e3, 4),
+                                       "note": "UDP_POSE_LANES=1: the whole batch as one launch sequence (round 2's configuration)"}
+            del hp_1
+        finally:
+            if saved is None:
+                os.environ.pop("UDP_POSE_LANES", None)
+            else:
+                os.environ["UDP_POSE_LANES"] = saved
+
     metric = {"w32": "images/sec HRNet-W32 256x192 (infer+decode)", "w48": "images/sec HRNet-W48 384x288 (infer+decode)",
               "rsn18": "images/sec RSN-18 256x192 + UDP offset decode (infer+decode)"}[args.model]
     line = {"metric": metric, "value": round(value, 1), "unit": "images/s",

@@ -205,6 +205,40 @@ def test_w32_batch64_properties(w32_gaussian, dtype):
     assert torch.equal(mirrored, raw[64:68])                      # in-kernel mirror == explicit flip
 
 
+@pytest.mark.parametrize("n,flip", [(64, True), (17, True), (33, False), (16, True)])
+def test_sub_batch_lanes_change_no_number(w32_gaussian, n, flip):
+    """udp_hrnet_forward runs a split-fp16 batch of 16 crops or more as two sub-batch lanes (two hipGraphs, the second
+    on an internal stream beside the first, mirrored rows copied into place; udp_hrnet_lanes).  The heat-maps are those
+    of one lane, bit for bit -- even and odd splits, with and without the flip test, replayed twice (the second replay
+    runs while nothing orders it behind the first but the join)."""
+    import ctypes as C
+    from udp_pose_amd import _lib
+    sd, _ = w32_gaussian
+    x = torch.from_numpy(synth.synth_crops(8, 256, 192, seed=71)).cuda().repeat((n + 7) // 8, 1, 1, 1)[:n].contiguous()
+    x += 0.01 * torch.randn(x.shape, device="cuda", generator=torch.Generator("cuda").manual_seed(n))
+    out = {}
+    saved = os.environ.get("UDP_POSE_LANES")
+    try:
+        for lanes in ("1", "2"):
+            os.environ["UDP_POSE_LANES"] = lanes
+            net = MODELS["pose_hrnet"](_cfg(synth.W32_EXTRA, 17, "gaussian"), is_train=False, dtype="f16x2")
+            net.load_state_dict(sd).to("cuda")
+            a = net.raw_forward(x, flip_test=flip).clone()
+            b = net.raw_forward(x, flip_test=flip).clone()
+            assert torch.equal(a, b) and torch.isfinite(a).all()
+            handle = net._compiled[(256, 192)][0]
+            assert _lib.lib().udp_hrnet_lanes(handle, C.c_int(n)) == int(lanes)
+            out[lanes] = a
+            del net
+    finally:
+        if saved is None:
+            os.environ.pop("UDP_POSE_LANES", None)
+        else:
+            os.environ["UDP_POSE_LANES"] = saved
+    assert out["1"].shape == (n * (2 if flip else 1), 17, 64, 48)
+    assert torch.equal(out["1"], out["2"])
+
+
 def test_w32_bf16_mode_accuracy(golden_dir, w32_gaussian):
     """bf16 storage (fp32 accumulate) is REDUCED PRECISION and not a parity mode: this is a sanity bound on what it
     does to the (noise-like) reference heat-maps, far outside the 1e-3 / arg-max contract that the fp32 and
