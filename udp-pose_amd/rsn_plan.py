@@ -14,6 +14,8 @@ zero bias, ReLU).  The ``a + b`` that precedes most 3x3 convs is one element-wis
 """
 import torch
 
+import os
+
 from . import _lib
 from .hrnet_plan import HRNetProgram, _round_up, encode_weights
 
@@ -36,8 +38,10 @@ class RSNProgram(HRNetProgram):
         s = g / torch.sqrt(var + 1e-5)
         return (w * s[:, None, None, None]).to(torch.float32), ((b - mean) * s + beta).to(torch.float32)
 
-    def _pack(self, w, b, out_map=None, in_map=None, cout_t=None, cin_t=None):
-        """Pack to [k*k][cout_pad][cin_t]; out_map / in_map scatter real channels to padded positions."""
+    def _pack(self, w, b, out_map=None, in_map=None, cout_t=None, cin_t=None, ws=False):
+        """Pack to [k*k][cout_pad][cin_t]; out_map / in_map scatter real channels to padded positions.  ``ws``: the
+        fragment-major split-fp16 layout of the weight-stationary kernels (udp_conv_op.wfmt = 1), as HRNetProgram packs
+        its convs."""
         cout, cin, kh, kw = w.shape
         cout_t = cout_t or cout
         cin_t = cin_t or cin
@@ -50,12 +54,18 @@ class RSNProgram(HRNetProgram):
         wp[:, oi[:, None], ii[None, :]] = w.permute(2, 3, 0, 1).reshape(kh * kw, cout, cin)
         bp = torch.zeros(cout_pad, dtype=torch.float32)
         bp[oi] = b
-        wbytes = encode_weights(wp, self.dtype)
+        self._wexp = 0
+        if ws:
+            from .f16x2 import pack_weights_ws
+            packed, self._wexp = pack_weights_ws(wp)
+            wbytes = packed.numpy().tobytes()
+        else:
+            wbytes = encode_weights(wp, self.dtype)
         return self._put(wbytes), self._put(bp.numpy().tobytes()), cout_t, cin_t, kh, cout_pad
 
     # ---- emission ------------------------------------------------------------------------------
     def _op(self, kind, x, out, name, ks=1, stride=1, relu=0, cin=None, cout=None, cout_pad=None, res=None,
-            w_off=0, b_off=0, in_coff=0, out_coff=0, res_coff=0, hout=None, wout=None):
+            w_off=0, b_off=0, in_coff=0, out_coff=0, res_coff=0, hout=None, wout=None, wfmt=0, wexp=0):
         cin = cin if cin is not None else x.c
         cout = cout if cout is not None else out.c
         self._ops.append(dict(kind=kind, ks=ks, stride=stride, relu=int(relu), cin=cin, cout=cout,
@@ -65,12 +75,15 @@ class RSNProgram(HRNetProgram):
                               w_off=w_off, b_off=b_off, name=name, in_coff=in_coff,
                               in_pitch=x.c if x is not None else 0, out_coff=out_coff,
                               out_pitch=out.c if out is not None else 0, res_coff=res_coff,
-                              res_pitch=res.c if res is not None else 0))
+                              res_pitch=res.c if res is not None else 0, wfmt=wfmt, wexp=wexp))
 
     def _conv_v(self, x, name, out=None, ks=None, stride=1, relu=True, res=None, in_coff=0, cin_view=None,
                 out_coff=0, out_map=None, in_map=None, cout_t=None, cin_t=None, to_output=False):
         w, b = self._fold_cbr(name)
-        w_off, b_off, cout, cin, k, cout_pad = self._pack(w, b, out_map, in_map, cout_t, cin_t)
+        # split-fp16 3x3 / 1x1 convs on the weight-stationary kernels (UDP_POSE_RSN_WS=0: the LDS-staged kernel, A/B)
+        ws = (self.use_ws and not to_output and int(w.shape[2]) in (1, 3) and stride in (1, 2)
+              and os.environ.get("UDP_POSE_RSN_WS", "1") != "0")
+        w_off, b_off, cout, cin, k, cout_pad = self._pack(w, b, out_map, in_map, cout_t, cin_t, ws=ws)
         if cin_view is not None and cin_view != cin:
             raise ValueError("%s: view has %d channels, weights expect %d" % (name, cin_view, cin))
         pad = k // 2
@@ -79,7 +92,8 @@ class RSNProgram(HRNetProgram):
         if out is None and not to_output:
             out = self._new(cout, ho, wo)
         self._op(_lib.UDP_OP_CONV, x, out, name, ks=k, stride=stride, relu=relu, cin=cin, cout=cout, cout_pad=cout_pad,
-                 res=res, w_off=w_off, b_off=b_off, in_coff=in_coff, out_coff=out_coff, hout=ho, wout=wo)
+                 res=res, w_off=w_off, b_off=b_off, in_coff=in_coff, out_coff=out_coff, hout=ho, wout=wo,
+                 wfmt=int(ws), wexp=self._wexp)
         return out
 
     def _add(self, a, a_coff, b, b_coff, c, name):
