@@ -1637,25 +1637,197 @@ int describe_bilinear(const ConvParams& p, int dtype, Launch* out) {
   return describe_elementwise(p, dtype, &bilinear_ac_kernel<float>, &bilinear_ac_kernel<__bf16>, &bilinear_ac_kernel<H2>, out);
 }
 
+// 7x7 stride-2 stem (RSN, network.py:400-412) with the input window staged through LDS.  stem_mfma_k<T, 7> gathers a
+// lane's 40 K values per 16-pixel tile straight from global memory (scattered 4-byte loads: 670 us per 128 images, 12 %
+// of the RSN-18 step, against 472 MB of input + output = ~120 us of HBM time).  Here a workgroup owns a tile of 2 output
+// rows x 32 output columns: its 9 x 69 x 3 fp32 input window is loaded coalesced (register-staged one tile ahead,
+// mirrored columns for the flip-test half, zeros outside the image), and the lanes gather from LDS.  Same GEMM
+// (K = 147 -> 160, five k-steps, weights fragment-major in LDS), same summation order, same results.
+template <typename T>
+__global__ __launch_bounds__(256) void stem7_lds_kernel(const ConvParams p) {
+  constexpr bool SPLIT = std::is_same<T, H2>::value;
+  constexpr int KS = 7, K = KS * KS * 3, NS = (K + 31) / 32, PAD = 3, WPL = SPLIT ? 2 : 1;
+  constexpr int TR = 2, TC = 32, WR = 2 * TR + 5, WC = 2 * TC + 5, WP = 72, WIN = 3 * WR * WC, PER = (WIN + 255) / 256;
+  using E = typename std::conditional<SPLIT, _Float16, __bf16>::type;
+  using Frag = typename std::conditional<SPLIT, f16x8, bf16x8>::type;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  E* wl = reinterpret_cast<E*>(smem);
+  float* win = reinterpret_cast<float*>(smem + NS * 4 * WPL * 1024);       // [ch][WR][WP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kg = lane >> 4;
+  const float* wg = reinterpret_cast<const float*>(p.wgt);
+  for (int e = tid; e < NS * 4 * WPL * 512; e += 256) {
+    const int j = e & 7, ln = (e >> 3) & 63, pl = (e >> 9) % WPL, nb = ((e >> 9) / WPL) & 3, st = (e >> 9) / (WPL * 4);
+    const int k = 32 * st + 8 * (ln >> 4) + j;
+    const int cout = 16 * ((ln & 15) >> 2) + 4 * nb + (ln & 3);
+    const float w = k < K ? wg[k * 64 + cout] : 0.f;
+    if constexpr (SPLIT) {
+      const _Float16 hi = (_Float16)w;
+      wl[e] = pl == 0 ? hi : (_Float16)((w - (float)hi) * kLoScale);
+    } else {
+      wl[e] = (__bf16)w;
+    }
+  }
+  const int cbase = 16 * kg;
+  f32x4 bias[4];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) bias[nb] = *reinterpret_cast<const f32x4*>(p.bias + cbase + 4 * nb);
+  // per k-step the lane's 8 K values as 16-bit window offsets (ch * WR + ky) * WP + kx, 0xFFFF = K padding
+  unsigned koff[NS][4];
+#pragma unroll
+  for (int st = 0; st < NS; ++st)
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      unsigned v = 0;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int k = 32 * st + 8 * kg + 2 * h + q, tap = k / 3;
+        const unsigned c = k < K ? (unsigned)(((k % 3) * WR + tap / KS) * WP + tap % KS) : 0xFFFFu;
+        v |= c << (16 * q);
+      }
+      koff[st][h] = v;
+    }
+  const int tiles_x = (p.Wout + TC - 1) / TC, tiles_y = (p.Hout + TR - 1) / TR;
+  const long ntile = (long)p.N * tiles_y * tiles_x;
+  const size_t plane = (size_t)p.Hin * p.Win;
+  // the window of tile t, this thread's PER elements (coalesced along x), into registers
+  auto fetch = [&](long t, float (&v)[PER]) __attribute__((always_inline)) {
+    const int tx = (int)(t % tiles_x);
+    const long t2 = t / tiles_x;
+    const int ty = (int)(t2 % tiles_y), n = (int)(t2 / tiles_y);
+    const bool mirror = n >= p.flip_from;
+    const float* in = reinterpret_cast<const float*>(p.in) + (size_t)(mirror ? n - p.flip_from : n) * 3 * plane;
+    const int gy0 = ty * TR * 2 - PAD, gx0 = tx * TC * 2 - PAD;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = tid + 256 * i;
+      const int ch = e / (WR * WC), rem = e - ch * (WR * WC);
+      const int iy = rem / WC, ix = rem - iy * WC;
+      const int gy = gy0 + iy, gx = gx0 + ix;
+      const bool ok = e < WIN && gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win;
+      v[i] = ok ? in[(size_t)ch * plane + (size_t)gy * p.Win + (mirror ? p.Win - 1 - gx : gx)] : 0.f;
+    }
+  };
+  auto put = [&](const float (&v)[PER]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = tid + 256 * i;
+      if (e < WIN) {
+        const int ch = e / (WR * WC), rem = e - ch * (WR * WC);
+        const int iy = rem / WC, ix = rem - iy * WC;
+        win[(ch * WR + iy) * WP + ix] = v[i];
+      }
+    }
+  };
+  const int r = wave >> 1, xl = (wave & 1) * 16 + li;          // the lane's output pixel inside the tile
+  const int wbase = (2 * r) * WP + 2 * xl;
+  float pre[PER];
+  long tile = blockIdx.x;
+  if (tile < ntile) fetch(tile, pre);
+  for (; tile < ntile; tile += gridDim.x) {
+    __syncthreads();                       // the previous tile's gathers are done (and, first time, the weights are in)
+    put(pre);
+    __syncthreads();
+    if (tile + gridDim.x < ntile) fetch(tile + gridDim.x, pre);          // next window flies under this tile's MFMAs
+    const int tx = (int)(tile % tiles_x);
+    const long t2 = tile / tiles_x;
+    const int ty = (int)(t2 % tiles_y), n = (int)(t2 / tiles_y);
+    const int yo = ty * TR + r, xo = tx * TC + xl;
+    const bool okp = yo < p.Hout && xo < p.Wout;
+    f32x4 acc[4], accx[SPLIT ? 4 : 1];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) acc[nb] = bias[nb];
+#pragma unroll
+    for (int nb = 0; nb < (SPLIT ? 4 : 1); ++nb) accx[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      Frag hi, lo;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned ko = (koff[st][j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+        const float v = ko != 0xFFFFu ? win[wbase + (int)ko] : 0.f;
+        hi[j] = (E)v;
+        lo[j] = (E)((v - (float)hi[j]) * (SPLIT ? kLoScale : 1.f));
+      }
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        const Frag wh = *reinterpret_cast<const Frag*>(wl + ((st * 4 + nb) * WPL) * 512 + lane * 8);
+        if constexpr (SPLIT) {
+          const Frag wlo = *reinterpret_cast<const Frag*>(wl + ((st * 4 + nb) * WPL + 1) * 512 + lane * 8);
+          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, hi, acc[nb], 0, 0, 0);
+          accx[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, lo, accx[nb], 0, 0, 0);
+          accx[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo, hi, accx[nb], 0, 0, 0);
+        } else {
+          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, hi, acc[nb], 0, 0, 0);
+          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, lo, acc[nb], 0, 0, 0);
+        }
+      }
+    }
+    if constexpr (SPLIT) {
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) acc[nb] += accx[nb] * kLoInv;
+    }
+    if (p.relu) {
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[nb][q] = acc[nb][q] > 0.f ? acc[nb][q] : 0.f;
+    }
+    if (okp) {
+      const size_t pix = ((size_t)n * p.Hout + yo) * p.Wout + xo;
+      if constexpr (SPLIT) {
+        unsigned char* o = reinterpret_cast<unsigned char*>(p.out) + pix * 256 + cbase * 2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          f16x8 oh, ol;
+          h2_split8(acc[2 * h], acc[2 * h + 1], oh, ol);
+          *reinterpret_cast<f16x8*>(o + 16 * h) = oh;
+          *reinterpret_cast<f16x8*>(o + 128 + 16 * h) = ol;
+        }
+      } else {
+        __bf16* o = reinterpret_cast<__bf16*>(p.out) + pix * 64 + cbase;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          bf16x8 ov;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            ov[q] = (__bf16)acc[2 * h][q];
+            ov[4 + q] = (__bf16)acc[2 * h + 1][q];
+          }
+          *reinterpret_cast<bf16x8*>(o + 8 * h) = ov;
+        }
+      }
+    }
+  }
+}
+
 int describe_stem7(const ConvParams& p, int dtype, Launch* out) {
   if (p.Cout != 64) return fail(UDP_ERR_UNSUPPORTED, "7x7 stem expects 64 output channels, got %d", p.Cout);
   const long total = (long)p.N * p.Hout * p.Wout;
   if (dtype != UDP_F32 && getenv("UDP_POSE_STEM_VALU") == nullptr) {
     // bf16 / split fp16: the 7x7 stem as a K = 147 -> 160 GEMM on the matrix pipe
     static bool attr_set = false;
-    const void* kb = reinterpret_cast<const void*>(&stem_mfma_k<__bf16, 7>);
-    const void* kh = reinterpret_cast<const void*>(&stem_mfma_k<H2, 7>);
+    const bool gather = getenv("UDP_POSE_STEM7_GATHER") != nullptr;        // A/B: the global-gather form
+    const void* kb = gather ? reinterpret_cast<const void*>(&stem_mfma_k<__bf16, 7>) : reinterpret_cast<const void*>(&stem7_lds_kernel<__bf16>);
+    const void* kh = gather ? reinterpret_cast<const void*>(&stem_mfma_k<H2, 7>) : reinterpret_cast<const void*>(&stem7_lds_kernel<H2>);
     if (!attr_set) {
-      UDP_HIP_CHECK(hipFuncSetAttribute(kb, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-      UDP_HIP_CHECK(hipFuncSetAttribute(kh, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+      for (const void* k : {reinterpret_cast<const void*>(&stem_mfma_k<__bf16, 7>), reinterpret_cast<const void*>(&stem_mfma_k<H2, 7>),
+                            reinterpret_cast<const void*>(&stem7_lds_kernel<__bf16>), reinterpret_cast<const void*>(&stem7_lds_kernel<H2>)})
+        UDP_HIP_CHECK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
       attr_set = true;
     }
-    const long ntile = (total + 15) / 16;
     out->fn = dtype == UDP_F16X2 ? kh : kb;
-    out->grid = dim3((unsigned)((ntile + 3) / 4 < 1024 ? (ntile + 3) / 4 : 1024));
     out->block = dim3(256);
     out->lds = 5 * 4 * (dtype == UDP_F16X2 ? 2 : 1) * 1024;
     out->p = p;
+    if (gather) {
+      const long ntile = (total + 15) / 16;
+      out->grid = dim3((unsigned)((ntile + 3) / 4 < 1024 ? (ntile + 3) / 4 : 1024));
+    } else {
+      const long ntile = (long)p.N * ((p.Hout + 1) / 2) * ((p.Wout + 31) / 32);
+      out->grid = dim3((unsigned)(ntile < 1024 ? ntile : 1024));
+      out->lds += 3 * 9 * 72 * sizeof(float);
+    }
     return UDP_OK;
   }
   out->fn = dtype == UDP_F32     ? reinterpret_cast<const void*>(&stem7_conv_kernel<float>)
