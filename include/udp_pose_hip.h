@@ -146,8 +146,8 @@ int udp_hrnet_create(const udp_conv_op* ops_host, int n_ops, const int64_t* buf_
 size_t udp_hrnet_workspace_bytes(const udp_hrnet* h, int n, int flip_test);
 /* Sub-batch lanes udp_hrnet_forward(use_graph != 0) runs a batch of `n` images in: 2 = the batch is cut in two halves,
  * each replayed as its own hipGraph, the second on an internal stream beside the first (fork / join on the caller's
- * stream; results are those of one lane, images are independent); 1 otherwise.  Two lanes: UDP_F16X2, inputs up to
- * 256x192, n >= 16 (environment UDP_POSE_LANES=1 / 2 forces one / two). */
+ * stream; results are those of one lane, images are independent); 1 otherwise.  Two lanes: UDP_F16X2 / UDP_BF16, inputs
+ * up to 256x192, n >= 16 (environment UDP_POSE_LANES=1 / 2 forces one / two). */
 int udp_hrnet_lanes(const udp_hrnet* h, int n);
 /* in_nchw: fp32 [n,3,in_h,in_w].  heatmaps_nchw: fp32 [n*(flip_test?2:1), C, in_h/4, in_w/4];
  * with flip_test rows n..2n-1 are the raw outputs for the mirrored inputs (fuse them with

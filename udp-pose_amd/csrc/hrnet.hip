@@ -248,13 +248,13 @@ static size_t out_bytes(const udp_hrnet* h, int images) {
 // the chip idle between a kernel's last workgroups and its successor's first HBM round trip (42 % of the workgroup
 // slot time of the dominant launch is outside its MFMA loop, NOTES.md); a second, independent chain fills those gaps.
 // Images are independent (same result for an image whatever batch it arrives in -- tests/test_gpu_e2e.py), so the
-// split changes no number.  Default: split-fp16 mode, inputs up to 256x192, 16 crops or more; UDP_POSE_LANES=1 / 2
-// forces it off / on.
+// split changes no number.  Default: split-fp16 and bf16 modes (bf16: 13.2 -> 14.3 k), inputs up to 256x192, 16 crops
+// or more; UDP_POSE_LANES=1 / 2 forces it off / on.
 static bool split_ok(const udp_hrnet* h, int n) {
-  if (h->dtype != UDP_F16X2 || n < 16) return false;
+  if (n < 16) return false;
   const char* e = getenv("UDP_POSE_LANES");
   if (e) return atoi(e) >= 2;
-  return (long)h->in_h * h->in_w <= 256L * 192L;
+  return h->dtype != UDP_F32 && (long)h->in_h * h->in_w <= 256L * 192L;   // (fp32 mode: 2.86 -> 2.70 k with two lanes)
 }
 extern "C" int udp_hrnet_lanes(const udp_hrnet* h, int n) { return h && n > 0 && split_ok(h, n) ? 2 : 1; }
 extern "C" size_t udp_hrnet_workspace_bytes(const udp_hrnet* h, int n, int flip_test) {
