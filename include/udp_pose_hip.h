@@ -131,7 +131,10 @@ typedef struct udp_conv_op {
   int32_t wexp;            /* wfmt 1: power-of-two scale of the stored weights, chosen so that max |w| * 2^wexp lies in
                               [2^13, 2^14) (|wexp| <= 40; 0 for an all-zero tensor).  The kernel keeps one fp32
                               accumulator of conv * 2^wexp and multiplies by 2^-wexp in its epilogue. */
-  int32_t reserved0;
+  int32_t in_stuff2;       /* udp_conv2d_fused / _group, fp32 and bf16 storage: 1 = the input tensor is [n][hin/2][win/2][cin] and is read
+                              as its zero-stuffed image (pixel (2i, 2j) = tensor pixel (i, j), zeros elsewhere): the input gradient of
+                              a stride-2 conv = this stride-1 conv over the stuffed output gradient, without materialising it
+                              (udp_zero_stuff2 + 4x the bytes); hin, win even.  0 elsewhere. */
 } udp_conv_op;
 
 typedef struct udp_hrnet udp_hrnet; /* opaque */

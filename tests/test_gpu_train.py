@@ -232,6 +232,37 @@ def test_graphed_train_step_equals_eager_steps():
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_stride2_input_gradient_reads_the_stuffed_view(dtype):
+    """The input gradient of a stride-2 conv is a stride-1 conv over the output gradient on the even grid of a 2x image.
+    The conv kernels read dy AS that zero-stuffed image (udp_conv_op.in_stuff2: odd rows / columns come out of the
+    staging as zeros) instead of a materialised copy (udp_zero_stuff2): same MFMAs on the same operands, so three
+    training steps end with the same parameters bit for bit, in both storage modes."""
+    cfg = {"MODEL": {"EXTRA": EXTRA, "NUM_JOINTS": 5, "TARGET_TYPE": "gaussian"}}
+    sd0 = synth.synth_state_dict(EXTRA, 5, "gaussian", seed=3)
+    batches = [make_batch("gaussian", n=6, seed=70 + k) for k in range(3)]
+    outs = []
+    saved = os.environ.get("UDP_POSE_ZERO_STUFF")
+    try:
+        for materialise in (True, False):
+            if materialise:
+                os.environ["UDP_POSE_ZERO_STUFF"] = "1"
+            else:
+                os.environ.pop("UDP_POSE_ZERO_STUFF", None)
+            tr = HRNetTrainer(cfg, {k: v.clone() for k, v in sd0.items()}, device="cuda", dtype=dtype, lr=1e-3)
+            for x, tg, tw in batches:
+                tr.train_step(x.cuda(), tg.cuda(), tw.cuda())
+            torch.cuda.synchronize()
+            outs.append(tr.flat.cpu().numpy().copy())
+            assert np.isfinite(outs[-1]).all()
+    finally:
+        if saved is None:
+            os.environ.pop("UDP_POSE_ZERO_STUFF", None)
+        else:
+            os.environ["UDP_POSE_ZERO_STUFF"] = saved
+    np.testing.assert_array_equal(outs[0], outs[1])
+
+
 def test_sum_nodes_and_their_gradients():
     """relu(a + up2(b) + up4(c)) forward through udp_ew_accumulate, backward through relu_bwd / upsample_bwd."""
     L = _lib.lib()

@@ -54,7 +54,7 @@ class ConvOp(C.Structure):
         ("res_coff", C.c_int32), ("res_pitch", C.c_int32),
         ("lane", C.c_int32), ("n_wait", C.c_int32), ("wait_op", C.c_int32 * 8),
         ("w2_off", C.c_int64), ("b2_off", C.c_int64),
-        ("group", C.c_int32), ("wfmt", C.c_int32), ("wexp", C.c_int32), ("reserved0", C.c_int32),
+        ("group", C.c_int32), ("wfmt", C.c_int32), ("wexp", C.c_int32), ("in_stuff2", C.c_int32),
     ]
 
 

@@ -82,6 +82,7 @@ struct ConvParams {
   int sbuf;              // conv_mfma_kernel: one stage buffer instead of two (set by conv_choose_tile)
   int wfmt;              // udp_conv_op.wfmt: 1 = fragment-major split-fp16 weights (conv_ws_h2_kernel)
   int wexp;              // udp_conv_op.wexp: those weights are stored scaled by 2^wexp
+  int in_stuff2;         // udp_conv_op.in_stuff2: conv_mfma_kernel reads the [Hin/2][Win/2] input as its zero-stuffed image
   double* bn_ws;         // training: per-workgroup BatchNorm partial sums of the output, [tile][2*Cout] (or null)
 };
 

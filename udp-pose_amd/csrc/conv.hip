@@ -160,7 +160,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int ti
 
   const unsigned out_pix = (unsigned)p.N * p.Hout * p.Wout;
   const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<void*>(p.in), 0, (unsigned)p.N * p.Hin * p.Win * inpb, 0x00020000);
+      const_cast<void*>(p.in), 0, (unsigned)p.N * (p.Hin >> p.in_stuff2) * (p.Win >> p.in_stuff2) * inpb, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void*>(p.wgt), 0, (unsigned)TAPS * p.CoutPad * cinb, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(
@@ -183,8 +183,12 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int ti
       const int g = fdiv20(tmp, p.mIH);
       const int iy = tmp - (int)__umul24(g, IH);
       const int n = n0 + g, gy = gy0 + iy, gx = gx0 + ix;
-      const bool ok = row < npix_in && n < p.N && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win;
-      const unsigned pix = __umul24(__umul24(n, p.Hin) + gy, p.Win) + gx;
+      bool ok = row < npix_in && n < p.N && (unsigned)gy < (unsigned)p.Hin && (unsigned)gx < (unsigned)p.Win;
+      unsigned pix = __umul24(__umul24(n, p.Hin) + gy, p.Win) + gx;
+      if (p.in_stuff2) {      // zero-stuffed view of a half-resolution tensor: odd rows / columns are zeros (wave-uniform flag)
+        ok = ok && !((gy | gx) & 1);
+        pix = __umul24(__umul24(n, p.Hin >> 1) + (gy >> 1), p.Win >> 1) + (gx >> 1);
+      }
       off = ok ? pix * inpb + p.in_coff * ESZ + ((spart ^ swz<T>(row)) << 4) : kOobOff;
     }
     src_off[i] = off;
@@ -1367,7 +1371,7 @@ static int describe_persist_mbw(const ConvParams& p, int mbw, size_t lds, int gr
 // Persistent single-chunk form (bf16, Cin = 32): returns 1 when it does not apply.
 static int describe_persist(const ConvParams& p, int ks, int stride, int nb, int mbw, Launch* out) {
   const int npix = p.G * p.IH * p.IW;
-  if (p.out_nchw_f32 || p.Cin != 32 || npix > MAXGP * 64 || p.ntiles >= 65536 || p.bn_ws) return 1;
+  if (p.out_nchw_f32 || p.Cin != 32 || npix > MAXGP * 64 || p.ntiles >= 65536 || p.bn_ws || p.in_stuff2) return 1;
   if (p.in_pitch != p.Cin || p.in_coff || p.out_pitch != p.Cout || p.out_coff || (p.res && (p.res_pitch != p.Cout || p.res_coff)))
     return 1;                                         // channel-slice views: generic kernel
   const size_t lds = (size_t)(ks * ks * nb * 16 + 2 * ((npix + 15) / 16) * 16) * ROWB;
@@ -1455,6 +1459,8 @@ int describe_conv(ConvParams p, int dtype, int ks, int stride, Launch* out) {
   if (false ||
       p.N >= 2048)
     return fail(UDP_ERR_UNSUPPORTED, "conv tensor exceeds the 2 GiB the 32-bit buffer offsets cover; split the batch");
+  if (p.in_stuff2 && (dtype == UDP_F16X2 || stride != 1 || (p.Hin & 1) || (p.Win & 1)))
+    return fail(UDP_ERR_UNSUPPORTED, "in_stuff2: a stride-1 fp32 / bf16 conv over an even-sized stuffed image");
   if (p.wfmt == 1) {
     if (dtype != UDP_F16X2) return fail(UDP_ERR_ARG, "wfmt 1 (fragment-major weights) needs UDP_F16X2");
     return describe_conv_ws(p, ks, stride, out);
@@ -1486,7 +1492,9 @@ int describe_conv_grouped(ConvParams p, int dtype, int ks, int stride, Launch* o
     // a launch of its own otherwise
     return describe_conv_ws(p, ks, stride, out, true);
   }
-  if (p.wfmt != 0 || (dtype != UDP_BF16 && dtype != UDP_F16X2) || (ks != 3 && ks != 1) || stride != 1 || p.out_nchw_f32 || p.nup || p.Cin % 16 || p.Cout % 16 || p.CoutPad % 32) return 1;
+  if (p.wfmt != 0 || (dtype != UDP_BF16 && dtype != UDP_F16X2) || (ks != 3 && ks != 1) || stride != 1 || p.out_nchw_f32 || p.nup || p.Cin % 16 || p.Cout % 16 || p.CoutPad % 32 ||
+      (p.in_stuff2 && dtype != UDP_BF16))
+    return 1;
   const size_t pix_esz = dtype == UDP_BF16 ? 2 : 4;
   if ((size_t)p.N * p.Hin * p.Win * p.in_pitch * pix_esz >= 0x7FFF0000u || (size_t)p.N * p.Hout * p.Wout * p.out_pitch * pix_esz >= 0x7FFF0000u ||
       (p.in_coff * 2) % 16 || (p.in_pitch * 2) % 16 ||

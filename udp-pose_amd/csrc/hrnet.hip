@@ -685,6 +685,7 @@ static int conv2d_params(const udp_conv_op* o, int dtype, int n, const void* in,
   p.relu = o->relu;
   p.wfmt = o->wfmt;
   p.wexp = o->wexp;
+  p.in_stuff2 = o->in_stuff2 ? 1 : 0;
   p.flip_from = n;
   p.in_pitch = o->in_pitch ? o->in_pitch : o->cin;
   p.in_coff = o->in_coff;

@@ -273,11 +273,19 @@ class HRNetTrainer:
             if not x.needs_grad:
                 return
             src, hh, ww = dy, ho, wo
+            stuffed = 0
             if stride == 2:
-                src = torch.empty(x.n * 4 * ho * wo * y.ck, dtype=self._tdt, device=self.device)
-                _lib.check(L.udp_zero_stuff2(dy.data_ptr(), x.n, ho, wo, y.ck, self._dt, src.data_ptr(), self._stream()))
+                # the input gradient of a stride-2 conv = a stride-1 conv over dy on the even grid of a 2x image; the
+                # conv kernel reads dy AS that zero-stuffed image (udp_conv_op.in_stuff2) instead of a materialised
+                # copy (udp_zero_stuff2: one more launch, 4x the bytes written and read; UDP_POSE_ZERO_STUFF=1 for A/B)
                 hh, ww = 2 * ho, 2 * wo
+                if os.environ.get("UDP_POSE_ZERO_STUFF"):
+                    src = torch.empty(x.n * 4 * ho * wo * y.ck, dtype=self._tdt, device=self.device)
+                    _lib.check(L.udp_zero_stuff2(dy.data_ptr(), x.n, ho, wo, y.ck, self._dt, src.data_ptr(), self._stream()))
+                else:
+                    stuffed = 1
             dop = self._conv_op(ks, 1, y.ck, x.ck, hh, ww, x.h, x.w)
+            dop.in_stuff2 = stuffed
             res = x.grad
             if res is None:
                 x.grad = self._like(x)
