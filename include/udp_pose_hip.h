@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UDP_POSE_ABI_VERSION 17
+#define UDP_POSE_ABI_VERSION 18
 
 enum udp_status {
   UDP_OK = 0,
@@ -135,6 +135,16 @@ typedef struct udp_conv_op {
                               as its zero-stuffed image (pixel (2i, 2j) = tensor pixel (i, j), zeros elsewhere): the input gradient of
                               a stride-2 conv = this stride-1 conv over the stuffed output gradient, without materialising it
                               (udp_zero_stuff2 + 4x the bytes); hin, win even.  0 elsewhere. */
+  /* Second outputs (udp_hrnet_* programs, UDP_F16X2 convs with wfmt 1 and an NHWC output): besides `out`, the epilogue
+   * writes out2_k = out + add2_k for k < n_out2 (0..2) -- the value AS STORED in `out` (22-bit split) plus channels
+   * [add2_coff, add2_coff + cout) of another tensor of the output's resolution -- into channels [out2_coff, +cout) of a
+   * third one.  The RSN bottleneck's element-wise sums between its 3x3 convs (RSN/exps/RSN18.coco/network.py:102-114:
+   * `out_2_1 = conv(spx[1] + out_1_1)` ...) ride in the epilogue of the conv that produces their second operand instead of
+   * being launches of their own; the numbers are those of UDP_OP_FUSE on the stored tensors, bit for bit.  With
+   * n_out2 > 0, out_buf may be UDP_BUF_NONE: only the sums are stored. */
+  int32_t n_out2;
+  int32_t out2_buf[2], out2_coff[2], out2_pitch[2];
+  int32_t add2_buf[2], add2_coff[2], add2_pitch[2];
 } udp_conv_op;
 
 typedef struct udp_hrnet udp_hrnet; /* opaque */

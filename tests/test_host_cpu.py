@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libudp_pose_hip.so does not export %s" % name
     assert declared == set(_lib.EXPORTS)
-    assert lib.udp_abi_version() == _lib.ABI_VERSION == 17
+    assert lib.udp_abi_version() == _lib.ABI_VERSION == 18
 
 
 def test_argument_validation_without_gpu():
@@ -115,6 +115,45 @@ def test_lanes_order_every_buffer_hazard():
     for i, o in enumerate(ops):
         reads = [b for b in [o.in_buf, o.res_buf] + [o.up_buf[u] for u in range(o.n_up)] if b >= 0]
         writes = [o.out_buf] if o.out_buf >= 0 else []
+        for b in reads:
+            for j, kind in touched.get(b, []):
+                assert kind == "r" or (hb[i] >> j) & 1, "unordered RAW on buffer %d: op %d -> %d" % (b, j, i)
+        for b in writes:
+            for j, kind in touched.get(b, []):
+                assert (hb[i] >> j) & 1, "unordered WA%s on buffer %d: op %d -> %d" % (kind.upper(), b, j, i)
+        for b in reads:
+            touched.setdefault(b, []).append((i, "r"))
+        for b in writes:
+            touched.setdefault(b, []).append((i, "w"))
+
+
+def test_rsn_program_second_outputs_keep_every_hazard_ordered():
+    """RSN-18 in split fp16: the bottleneck's element-wise sums ride in conv epilogues (udp_conv_op.n_out2: the conv also
+    writes out + addend slices; out_buf may be UDP_BUF_NONE).  No UDP_OP_FUSE is left inside the bottlenecks, every
+    second output / addend has a live buffer, and every RAW / WAR / WAW pair on a physical buffer -- second outputs and
+    their addends included -- is ordered by lane order + wait lists."""
+    from udp_pose_amd import rsn_plan
+    sd = synth.synth_rsn18_state_dict(51, seed=4)
+    prog = rsn_plan.RSNProgram(sd, 256, 192, "f16x2")
+    ops = prog.ops_array()
+    n = len(ops)
+    assert sum(o.n_out2 for o in ops) == 48 and sum(1 for o in ops if o.kind == _lib.UDP_OP_FUSE) == 0
+    assert sum(1 for o in ops if o.out_buf == _lib.UDP_BUF_NONE) == 24
+    hb, last = [0] * n, {}
+    for i, o in enumerate(ops):
+        m = 0
+        for j in [o.wait_op[k] for k in range(o.n_wait)] + ([last[o.lane]] if o.lane in last else []):
+            assert j < i
+            m |= hb[j] | (1 << j)
+        hb[i] = m
+        last[o.lane] = i
+    touched = {}
+    for i, o in enumerate(ops):
+        reads = [b for b in [o.in_buf, o.res_buf] + [o.up_buf[u] for u in range(o.n_up)] + [o.add2_buf[k] for k in range(o.n_out2)] if b >= 0]
+        writes = ([o.out_buf] if o.out_buf >= 0 else []) + [o.out2_buf[k] for k in range(o.n_out2)]
+        assert o.n_out2 == 0 or (o.kind == _lib.UDP_OP_CONV and o.wfmt == 1)
+        assert len(set(writes)) == len(writes)
+        assert o.ks != 3 or not (set(writes) & set(reads)), "op %d: a 3x3 conv writes a buffer it reads" % i
         for b in reads:
             for j, kind in touched.get(b, []):
                 assert kind == "r" or (hb[i] >> j) & 1, "unordered RAW on buffer %d: op %d -> %d" % (b, j, i)

@@ -84,6 +84,10 @@ struct ConvParams {
   int wexp;              // udp_conv_op.wexp: those weights are stored scaled by 2^wexp
   int in_stuff2;         // udp_conv_op.in_stuff2: conv_mfma_kernel reads the [Hin/2][Win/2] input as its zero-stuffed image
   double* bn_ws;         // training: per-workgroup BatchNorm partial sums of the output, [tile][2*Cout] (or null)
+  // udp_conv_op.n_out2: second outputs out2[k] = out (as stored) + add2[k] of the weight-stationary split-fp16 convs
+  void* out2[2];
+  const void* add2[2];
+  int nout2, out2_coff[2], out2_pitch[2], add2_coff[2], add2_pitch[2];
 };
 
 // Kernel argument of conv_mfma_multi: up to 4 independent convs in one launch (flat block index ->

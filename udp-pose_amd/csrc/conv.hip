@@ -1461,6 +1461,7 @@ int describe_conv(ConvParams p, int dtype, int ks, int stride, Launch* out) {
     return fail(UDP_ERR_UNSUPPORTED, "conv tensor exceeds the 2 GiB the 32-bit buffer offsets cover; split the batch");
   if (p.in_stuff2 && (dtype == UDP_F16X2 || stride != 1 || (p.Hin & 1) || (p.Win & 1)))
     return fail(UDP_ERR_UNSUPPORTED, "in_stuff2: a stride-1 fp32 / bf16 conv over an even-sized stuffed image");
+  if (p.nout2 && p.wfmt != 1) return fail(UDP_ERR_UNSUPPORTED, "second outputs need the weight-stationary split-fp16 conv (wfmt 1)");
   if (p.wfmt == 1) {
     if (dtype != UDP_F16X2) return fail(UDP_ERR_ARG, "wfmt 1 (fragment-major weights) needs UDP_F16X2");
     return describe_conv_ws(p, ks, stride, out);

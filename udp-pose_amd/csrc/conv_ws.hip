@@ -37,7 +37,7 @@ __device__ __forceinline__ void add_res_h2(f32x4 (&v)[NB], const ResH2<NB>& o) {
   for (int h = 0; h < NB / 2; ++h) h2_add8(v[2 * h], v[2 * h + 1], __builtin_bit_cast(f16x8, o.hi[h]), __builtin_bit_cast(f16x8, o.lo[h]));
 }
 
-template <int KS, int STRIDE, int PB, int CP, bool NCHW>
+template <int KS, int STRIDE, int PB, int CP, bool NCHW, bool OUT2 = false>
 __device__ __forceinline__ void conv_ws_body(const ConvParams& p, const int tile_id, const int cby) {
   using T = H2;
   constexpr int CK = 32, ESZ = 2, NB = 2, NW = 4;
@@ -80,8 +80,9 @@ __device__ __forceinline__ void conv_ws_body(const ConvParams& p, const int tile
   const unsigned npairs = (unsigned)p.CoutPad >> 5;
   const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void*>(p.wgt), 0, (unsigned)TAPS * nchunks * npairs * 4096u, 0x00020000);
+  // (no `out`: second outputs only, udp_conv_op.n_out2 -- a zero-length descriptor drops the stores)
   const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(
-      p.out, 0, NCHW ? out_pix * p.Cout * 4 : out_pix * outpb, 0x00020000);
+      p.out, 0, !p.out ? 0 : NCHW ? out_pix * p.Cout * 4 : out_pix * outpb, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_bias = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.bias), 0, (unsigned)p.CoutPad * 4u, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc(
@@ -342,6 +343,36 @@ __device__ __forceinline__ void conv_ws_body(const ConvParams& p, const int tile
           for (int q = 0; q < 4; ++q) v[nb][q] = v[nb][q] > 0.f ? v[nb][q] : 0.f;
       }
       store_vec_buf<T, NB>(r_out, ooff, out_lo, v);
+      // (only in the kernels of convs launched on their own: with this code the merged kernel spills 4 KB per lane)
+      if (OUT2 && p.nout2) {   // wave-uniform, rare (RSN bottleneck): out2_k = out AS STORED + add2_k (udp_conv_op.n_out2)
+        f16x8 sh, sl;
+        h2_split8(v[0], v[1], sh, sl);
+        f32x4 vr[NB];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          vr[0][q] = (float)sh[q] + (float)sl[q] * kLoInv;
+          vr[1][q] = (float)sh[4 + q] + (float)sl[4 + q] * kLoInv;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (u < p.nout2 && opix[i] >= 0) {
+            const size_t px = (size_t)opix[i];
+            const _Float16* a = reinterpret_cast<const _Float16*>(p.add2[u]) + px * (2 * (size_t)p.add2_pitch[u]) + p.add2_coff[u] + cbase;
+            const f16x8 ah8 = *reinterpret_cast<const f16x8*>(a), al8 = *reinterpret_cast<const f16x8*>(a + p.add2_pitch[u]);
+            f32x4 w[NB];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {      // fuse_sum_kernel's order: addend first, then the conv output
+              w[0][q] = ((float)ah8[q] + (float)al8[q] * kLoInv) + vr[0][q];
+              w[1][q] = ((float)ah8[4 + q] + (float)al8[4 + q] * kLoInv) + vr[1][q];
+            }
+            f16x8 oh, ol;
+            h2_split8(w[0], w[1], oh, ol);
+            _Float16* o2 = reinterpret_cast<_Float16*>(p.out2[u]) + px * (2 * (size_t)p.out2_pitch[u]) + p.out2_coff[u] + cbase;
+            *reinterpret_cast<f16x8*>(o2) = oh;
+            *reinterpret_cast<f16x8*>(o2 + p.out2_pitch[u]) = ol;
+          }
+        }
+      }
     }
   }
   UDP_STAMP(6);
@@ -381,7 +412,7 @@ template <int KS, int STRIDE, int PB, int CP, bool NCHW>
 __global__ __launch_bounds__(256, 2) void conv_ws_h2_kernel(const ConvParams p) {
   int tile, cby;
   ws_decode(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x, gridDim.y, tile, cby);   // dispatch order = flat index
-  conv_ws_body<KS, STRIDE, PB, CP, NCHW>(p, tile, cby);
+  conv_ws_body<KS, STRIDE, PB, CP, NCHW, KS == 3 && STRIDE == 1 && !NCHW>(p, tile, cby);
 }
 
 // Merged launch of up to 4 independent weight-stationary convs (same-depth convs of different HRNet branches):
@@ -557,7 +588,9 @@ int describe_conv_ws(ConvParams p, int ks, int stride, Launch* out, bool grouped
   if (ks == 1 && stride == 1) rc = describe_ws_pb<1, 1, false>(p, best.pb, best.cp, best.lds, out);
   if (ks == 1 && stride == 2) rc = describe_ws_pb<1, 2, false>(p, best.pb, best.cp, best.lds, out);
   if (rc == 1) return fail(UDP_ERR_UNSUPPORTED, "weight-stationary conv: no kernel for PB=%d CP=%d", best.pb, best.cp);
-  if (rc == UDP_OK && grouped && best.pb == 6 && stride == 1) {
+  if (rc == UDP_OK && p.nout2 && !(ks == 3 && stride == 1))
+    return fail(UDP_ERR_UNSUPPORTED, "second outputs: 3x3 stride-1 convs only");
+  if (rc == UDP_OK && grouped && best.pb == 6 && stride == 1 && !p.nout2) {
     out->groupable = 300 + ks * 10 + 6;        // storage/kernel family 3 = split fp16 weight-stationary
     out->ws_cp = best.cp;
   }

@@ -110,6 +110,8 @@ static int validate_op(const udp_hrnet* h, const udp_conv_op& o, int idx) {
       return fail(UDP_ERR_ARG, "op %d: output op must be a conv producing [C=%d,%d,%d]", idx, h->out_channels,
                   h->in_h / 4, h->in_w / 4);
     if (o.res_buf != UDP_BUF_NONE || o.n_up != 0) return fail(UDP_ERR_ARG, "op %d: output op takes no addends", idx);
+  } else if (o.out_buf == UDP_BUF_NONE && o.n_out2 > 0 && o.kind == UDP_OP_CONV) {
+    // only the second outputs are wanted (nothing reads the plain conv output): its stores are dropped
   } else if (!buf_ok(o.out_buf, out_need)) {
     return fail(UDP_ERR_ARG, "op %d: out_buf %d missing or too small", idx, o.out_buf);
   }
@@ -153,6 +155,17 @@ static int validate_op(const udp_hrnet* h, const udp_conv_op& o, int idx) {
     if (s < 1 || s > 5 || (o.hout & ((1 << s) - 1)) || (o.wout & ((1 << s) - 1)))
       return fail(UDP_ERR_ARG, "op %d: up_shift %d does not divide %dx%d", idx, s, o.hout, o.wout);
     if (!buf_ok(o.up_buf[u], (int64_t)(o.hout >> s) * (o.wout >> s) * o.cout)) return fail(UDP_ERR_ARG, "op %d: up_buf %d", idx, u);
+  }
+  if (o.n_out2 < 0 || o.n_out2 > 2) return fail(UDP_ERR_ARG, "op %d: n_out2", idx);
+  if (o.n_out2 && (o.kind != UDP_OP_CONV || o.wfmt != 1 || h->dtype != UDP_F16X2 || o.out_buf == UDP_BUF_OUTPUT))
+    return fail(UDP_ERR_UNSUPPORTED, "op %d: second outputs need a split-fp16 conv with fragment-major weights and an NHWC output", idx);
+  for (int k = 0; k < o.n_out2; ++k) {
+    const int op = o.out2_pitch[k] ? o.out2_pitch[k] : o.cout, ap = o.add2_pitch[k] ? o.add2_pitch[k] : o.cout;
+    if (o.out2_coff[k] < 0 || o.out2_coff[k] + o.cout > op || o.add2_coff[k] < 0 || o.add2_coff[k] + o.cout > ap ||
+        (o.out2_coff[k] | o.add2_coff[k] | op | ap) % 8)
+      return fail(UDP_ERR_ARG, "op %d: second output %d: channel views", idx, k);
+    if (!buf_ok(o.out2_buf[k], (int64_t)o.hout * o.wout * op) || !buf_ok(o.add2_buf[k], (int64_t)o.hout * o.wout * ap))
+      return fail(UDP_ERR_ARG, "op %d: second output %d: buffers", idx, k);
   }
   return UDP_OK;
 }
@@ -300,12 +313,21 @@ static int describe_all(const udp_hrnet* h, const float* in, int n, int flip, ch
     p.res_coff = o.res_coff;
     p.in = is_stem ? reinterpret_cast<const void*>(in) : buf(o.in_buf);
     p.out_nchw_f32 = o.out_buf == UDP_BUF_OUTPUT;
-    p.out = p.out_nchw_f32 ? reinterpret_cast<void*>(out) : buf(o.out_buf);
+    p.out = p.out_nchw_f32 ? reinterpret_cast<void*>(out) : o.out_buf == UDP_BUF_NONE ? nullptr : buf(o.out_buf);
     p.res = o.res_buf == UDP_BUF_NONE ? nullptr : buf(o.res_buf);
     p.nup = o.n_up;
     for (int u = 0; u < o.n_up; ++u) {
       p.up[u] = buf(o.up_buf[u]);
       p.up_shift[u] = o.up_shift[u];
+    }
+    p.nout2 = o.n_out2;
+    for (int k = 0; k < o.n_out2; ++k) {
+      p.out2[k] = buf(o.out2_buf[k]);
+      p.add2[k] = buf(o.add2_buf[k]);
+      p.out2_coff[k] = o.out2_coff[k];
+      p.out2_pitch[k] = o.out2_pitch[k] ? o.out2_pitch[k] : o.cout;
+      p.add2_coff[k] = o.add2_coff[k];
+      p.add2_pitch[k] = o.add2_pitch[k] ? o.add2_pitch[k] : o.cout;
     }
     if (is_stem || o.kind == UDP_OP_CONV) {
       p.wgt = h->weights + o.w_off;
@@ -683,6 +705,7 @@ static int conv2d_params(const udp_conv_op* o, int dtype, int n, const void* in,
   p.Cout = o->cout;
   p.CoutPad = o->cout_pad;
   p.relu = o->relu;
+  if (o->n_out2) return fail(UDP_ERR_UNSUPPORTED, "udp_conv2d_fused: second outputs (n_out2) exist in udp_hrnet programs only");
   p.wfmt = o->wfmt;
   p.wexp = o->wexp;
   p.in_stuff2 = o->in_stuff2 ? 1 : 0;

@@ -344,14 +344,20 @@ class HRNetProgram:
         self._ops[0]["lane"] = 0
         producer = {}
         readers = {}
+
+        def reads_of(op):        # every tensor the op reads (add2: addends of its second outputs, udp_conv_op.n_out2)
+            return [t for t in [op["inp"], op["res"]] + [u for u, _ in op["ups"]] + [a for a, _ in op.get("add2", [])]
+                    if t is not None]
+
         for idx, op in enumerate(self._ops):
             if op["out"] is not None:
                 if op["out"].id in producer:
                     readers.setdefault(op["out"].id, []).append(producer[op["out"].id])   # earlier slice writers
                 producer[op["out"].id] = idx
-            for t in [op["inp"], op["res"]] + [u for u, _ in op["ups"]]:
-                if t is not None:
-                    readers.setdefault(t.id, []).append(idx)
+            for t, _ in op.get("out2", []):
+                producer[t.id] = idx
+            for t in reads_of(op):
+                readers.setdefault(t.id, []).append(idx)
         last_use = {tid: max(r) for tid, r in readers.items()}
         free = {}             # elems -> [(buffer id, previous tenant tensor id)]
         self.buf_elems = []
@@ -359,14 +365,14 @@ class HRNetProgram:
         pending = []
         for idx, op in enumerate(self._ops):
             deps = set()
-            for t in [op["inp"], op["res"]] + [u for u, _ in op["ups"]]:
-                if t is not None and t.id in producer:
+            for t in reads_of(op):
+                if t.id in producer:
                     deps.add(producer[t.id])
             out = op["out"]
             if out is not None and out.id in phys:
                 deps.add(producer[out.id])      # later slice of a concat buffer: ordered after its other writers
                 out = None
-            if out is not None:
+            for out in ([out] if out is not None else []) + [t for t, _ in op.get("out2", [])]:
                 pool = free.get(out.elems, [])
                 pick = None
                 for k in range(len(pool) - 1, -1, -1):
@@ -390,8 +396,8 @@ class HRNetProgram:
             # must not be handed to a later member of the same group
             g = op.get("group", 0)
             nxt = self._ops[idx + 1].get("group", 0) if idx + 1 < len(self._ops) else 0
-            for t in [op["inp"], op["res"]] + [u for u, _ in op["ups"]]:
-                if t is not None and last_use.get(t.id) == idx and t.id in phys:
+            for t in reads_of(op):
+                if last_use.get(t.id) == idx and t.id in phys:
                     pending.append((t.elems, phys[t.id], t.id))
                     last_use[t.id] = -1
             if g == 0 or nxt != g:
@@ -409,10 +415,14 @@ class HRNetProgram:
                       "w_off", "b_off"):
                 setattr(o, f, op[f])
             o.in_buf = _lib.UDP_BUF_NONE if op["inp"] is None else self._phys[op["inp"].id]
-            o.out_buf = _lib.UDP_BUF_OUTPUT if op["out"] is None else self._phys[op["out"].id]
+            o.out_buf = (_lib.UDP_BUF_NONE if op.get("no_out") else _lib.UDP_BUF_OUTPUT) if op["out"] is None else self._phys[op["out"].id]
             o.res_buf = _lib.UDP_BUF_NONE if op["res"] is None else self._phys[op["res"].id]
             for f in ("in_coff", "in_pitch", "out_coff", "out_pitch", "res_coff", "res_pitch", "w2_off", "b2_off", "group", "wfmt", "wexp"):
                 setattr(o, f, op.get(f, 0))
+            o.n_out2 = len(op.get("out2", []))
+            for k, ((t2, c2), (ta, ca)) in enumerate(zip(op.get("out2", []), op.get("add2", []))):
+                o.out2_buf[k], o.out2_coff[k], o.out2_pitch[k] = self._phys[t2.id], c2, t2.c
+                o.add2_buf[k], o.add2_coff[k], o.add2_pitch[k] = self._phys[ta.id], ca, ta.c
             o.lane = op["lane"]
             o.n_wait = len(op["wait"])
             for k, d in enumerate(op["wait"]):

@@ -65,7 +65,8 @@ class RSNProgram(HRNetProgram):
 
     # ---- emission ------------------------------------------------------------------------------
     def _op(self, kind, x, out, name, ks=1, stride=1, relu=0, cin=None, cout=None, cout_pad=None, res=None,
-            w_off=0, b_off=0, in_coff=0, out_coff=0, res_coff=0, hout=None, wout=None, wfmt=0, wexp=0):
+            w_off=0, b_off=0, in_coff=0, out_coff=0, res_coff=0, hout=None, wout=None, wfmt=0, wexp=0,
+            out2=(), add2=(), no_out=False):
         cin = cin if cin is not None else x.c
         cout = cout if cout is not None else out.c
         self._ops.append(dict(kind=kind, ks=ks, stride=stride, relu=int(relu), cin=cin, cout=cout,
@@ -75,10 +76,14 @@ class RSNProgram(HRNetProgram):
                               w_off=w_off, b_off=b_off, name=name, in_coff=in_coff,
                               in_pitch=x.c if x is not None else 0, out_coff=out_coff,
                               out_pitch=out.c if out is not None else 0, res_coff=res_coff,
-                              res_pitch=res.c if res is not None else 0, wfmt=wfmt, wexp=wexp))
+                              res_pitch=res.c if res is not None else 0, wfmt=wfmt, wexp=wexp,
+                              out2=list(out2), add2=list(add2), no_out=no_out))
 
     def _conv_v(self, x, name, out=None, ks=None, stride=1, relu=True, res=None, in_coff=0, cin_view=None,
-                out_coff=0, out_map=None, in_map=None, cout_t=None, cin_t=None, to_output=False):
+                out_coff=0, out_map=None, in_map=None, cout_t=None, cin_t=None, to_output=False, sums=(), keep=True):
+        """``sums``: [(tensor, channel offset)] addends -- for each one the conv also writes (its stored output + that
+        slice) into a new tensor (udp_conv_op.n_out2) and returns ``(out, [sum tensors])``; ``keep=False``: nothing reads
+        the plain output, only the sums are stored."""
         w, b = self._fold_cbr(name)
         # split-fp16 3x3 / 1x1 convs on the weight-stationary kernels (UDP_POSE_RSN_WS=0: the LDS-staged kernel, A/B)
         ws = (self.use_ws and not to_output and int(w.shape[2]) in (1, 3) and stride in (1, 2)
@@ -89,12 +94,15 @@ class RSNProgram(HRNetProgram):
         pad = k // 2
         ho = (x.h + 2 * pad - k) // stride + 1
         wo = (x.w + 2 * pad - k) // stride + 1
-        if out is None and not to_output:
+        if sums and not ws:
+            raise ValueError("%s: second outputs need the weight-stationary split-fp16 conv" % name)
+        if out is None and not to_output and keep:
             out = self._new(cout, ho, wo)
+        s2 = [self._new(cout, ho, wo) for _ in sums]
         self._op(_lib.UDP_OP_CONV, x, out, name, ks=k, stride=stride, relu=relu, cin=cin, cout=cout, cout_pad=cout_pad,
                  res=res, w_off=w_off, b_off=b_off, in_coff=in_coff, out_coff=out_coff, hout=ho, wout=wo,
-                 wfmt=int(ws), wexp=self._wexp)
-        return out
+                 wfmt=int(ws), wexp=self._wexp, out2=[(t, 0) for t in s2], add2=list(sums), no_out=not keep)
+        return (out, s2) if sums else out
 
     def _add(self, a, a_coff, b, b_coff, c, name):
         """out[c channels] = a[a_coff:a_coff+c] + b[b_coff:b_coff+c] (no activation)."""
@@ -114,9 +122,28 @@ class RSNProgram(HRNetProgram):
         cat = self._new(4 * bp, s.h, s.w)
         pad_in = list(range(bch))
 
-        def c3(src, src_coff, name, out=None, out_coff=0):
+        def c3(src, src_coff, name, out=None, out_coff=0, sums=(), keep=True):
             return self._conv_v(src, p + ".conv_bn_relu" + name, out=out, in_coff=src_coff, out_coff=out_coff,
-                                out_map=pad_in, in_map=pad_in, cout_t=bp, cin_t=bp)
+                                out_map=pad_in, in_map=pad_in, cout_t=bp, cin_t=bp, sums=sums, keep=keep)
+
+        if self.use_ws and os.environ.get("UDP_POSE_RSN_WS", "1") != "0" and os.environ.get("UDP_POSE_RSN_FUSE_ADDS", "1") != "0":
+            # split-fp16: the six element-wise sums between the 3x3 convs (network.py:102-114) ride in the epilogue of the
+            # conv that produces their second operand (second outputs, udp_conv_op.n_out2) instead of being launches of
+            # their own -- 48 launches and a third of their traffic per forward; same numbers as the separate sums
+            _, (t21,) = c3(s, 0, "2_1_1", out=cat, out_coff=0, sums=[(s, bp)])           # cat[0]; + spx[1]
+            o21, (t31,) = c3(t21, 0, "2_2_1", sums=[(s, 2 * bp)])                        # out_2_1; + spx[2]
+            c3(o21, 0, "2_2_2", out=cat, out_coff=bp)                                    # out_2_2 -> cat[1]
+            _, (t32, t41) = c3(t31, 0, "2_3_1", sums=[(cat, bp), (s, 3 * bp)], keep=False)   # out_3_1 (+ cat[1]; + spx[3])
+            o32 = c3(t32, 0, "2_3_2")                                                    # out_3_2
+            c3(o32, 0, "2_3_3", out=cat, out_coff=2 * bp)                                # out_3_3 -> cat[2]
+            _, (t42,) = c3(t41, 0, "2_4_1", sums=[(o32, 0)], keep=False)                 # out_4_1 + out_3_2
+            _, (t43,) = c3(t42, 0, "2_4_2", sums=[(cat, 2 * bp)], keep=False)            # out_4_2 + cat[2]
+            o43 = c3(t43, 0, "2_4_3")
+            c3(o43, 0, "2_4_4", out=cat, out_coff=3 * bp)                                # out_4_4 -> cat[3]
+            r = x
+            if (p + ".downsample.conv.weight") in sd:
+                r = self._conv_v(x, p + ".downsample", stride=stride, relu=False)
+            return self._conv_v(cat, p + ".conv_bn_relu3", res=r, in_map=scatter, cin_t=4 * bp)
 
         c3(s, 0, "2_1_1", out=cat, out_coff=0)                                   # out_1_1 -> cat[0]
         o21 = c3(self._add(s, bp, cat, 0, bp, p + ".add21"), 0, "2_2_1")
