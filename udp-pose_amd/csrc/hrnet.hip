@@ -157,8 +157,8 @@ static int validate_op(const udp_hrnet* h, const udp_conv_op& o, int idx) {
     if (!buf_ok(o.up_buf[u], (int64_t)(o.hout >> s) * (o.wout >> s) * o.cout)) return fail(UDP_ERR_ARG, "op %d: up_buf %d", idx, u);
   }
   if (o.n_out2 < 0 || o.n_out2 > 2) return fail(UDP_ERR_ARG, "op %d: n_out2", idx);
-  if (o.n_out2 && (o.kind != UDP_OP_CONV || o.wfmt != 1 || h->dtype != UDP_F16X2 || o.out_buf == UDP_BUF_OUTPUT))
-    return fail(UDP_ERR_UNSUPPORTED, "op %d: second outputs need a split-fp16 conv with fragment-major weights and an NHWC output", idx);
+  if (o.n_out2 && (o.kind != UDP_OP_CONV || o.wfmt != 1 || h->dtype != UDP_F16X2 || o.out_buf == UDP_BUF_OUTPUT || o.cout % 8 || o.ks != 3 || o.stride != 1 || o.group))
+    return fail(UDP_ERR_UNSUPPORTED, "op %d: second outputs need an ungrouped 3x3 stride-1 split-fp16 conv with fragment-major weights, an NHWC output and cout %% 8 == 0", idx);
   for (int k = 0; k < o.n_out2; ++k) {
     const int op = o.out2_pitch[k] ? o.out2_pitch[k] : o.cout, ap = o.add2_pitch[k] ? o.add2_pitch[k] : o.cout;
     if (o.out2_coff[k] < 0 || o.out2_coff[k] + o.cout > op || o.add2_coff[k] < 0 || o.add2_coff[k] + o.cout > ap ||
