@@ -644,3 +644,32 @@ def test_rsn18_offset_batch64_properties(golden_dir, dtype):
                                            torch.from_numpy(s.astype(np.float64)), "offset", False, 4.0, True)
     np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
     np.testing.assert_allclose(preds.cpu().numpy(), rp, rtol=0, atol=1e-3)
+
+
+def test_rsn18_sums_in_conv_epilogues_equal_separate_sums(golden_dir):
+    """RSN-18 in split fp16: the six element-wise sums between the 3x3 convs of every bottleneck
+    (RSN/exps/RSN18.coco/network.py:102-114) ride in the epilogue of the conv that produces their second operand
+    (udp_conv_op.n_out2: second outputs = the output AS STORED + an addend slice; three convs per bottleneck store only
+    the sums).  Heat-maps of the 51-channel head at N = 24 with the flip test equal those of the program with separate
+    UDP_OP_FUSE launches (UDP_POSE_RSN_FUSE_ADDS=0), bit for bit; the fused program has 48 launches fewer."""
+    from udp_pose_amd.model import RSN18Hip
+    calib = dict(np.load(os.path.join(golden_dir, "bn_calib_rsn18_51.npz")))
+    sd = synth.synth_rsn18_state_dict(51, seed=4, bn_calib=calib)
+    x = torch.from_numpy(synth.synth_crops(8, 256, 192, seed=12)).cuda().repeat(3, 1, 1, 1)
+    x[8:] += 0.01 * torch.randn(16, 3, 256, 192, device="cuda", generator=torch.Generator("cuda").manual_seed(9))
+    out, nops = {}, {}
+    saved = os.environ.get("UDP_POSE_RSN_FUSE_ADDS")
+    try:
+        for fuse in ("0", "1"):
+            os.environ["UDP_POSE_RSN_FUSE_ADDS"] = fuse
+            net = RSN18Hip(51, dtype="f16x2").load_state_dict(sd).to("cuda")
+            out[fuse] = net.raw_forward(x, flip_test=True).clone()
+            nops[fuse] = len(net.program(256, 192).ops_array())
+            del net
+    finally:
+        if saved is None:
+            os.environ.pop("UDP_POSE_RSN_FUSE_ADDS", None)
+        else:
+            os.environ["UDP_POSE_RSN_FUSE_ADDS"] = saved
+    assert torch.isfinite(out["1"]).all() and nops["0"] - nops["1"] == 48
+    assert torch.equal(out["0"], out["1"])
