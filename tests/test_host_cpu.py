@@ -56,14 +56,23 @@ def test_taps_match_documented_opencv_rule():
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_program_census_matches_survey(dtype):
+def test_program_census_matches_survey(dtype, monkeypatch):
     sd = synth.synth_state_dict(synth.W32_EXTRA, 17, "gaussian", seed=0)
+    monkeypatch.setenv("UDP_POSE_NO_L1_CONCAT", "1")
+    plain = hrnet_plan.HRNetProgram(sd, synth.W32_EXTRA, 256, 192, dtype)
+    monkeypatch.delenv("UDP_POSE_NO_L1_CONCAT")
     prog = hrnet_plan.HRNetProgram(sd, synth.W32_EXTRA, 256, 192, dtype)
     kinds = [d[1] for d in prog.describe()]
     assert kinds.count(_lib.UDP_OP_STEM) == 1
     n_block = kinds.count(_lib.UDP_OP_BLOCK)       # bf16: the 32 BasicBlocks of the 32-channel branch are one launch each
     assert n_block == (32 if dtype == "bf16" else 0)
-    assert kinds.count(_lib.UDP_OP_STEM) + kinds.count(_lib.UDP_OP_CONV) + 2 * n_block == 294     # 294 convs
+    # 294 convs; layer1.0's conv3 and projection shortcut are ONE conv over the concatenated channels
+    assert kinds.count(_lib.UDP_OP_STEM) + kinds.count(_lib.UDP_OP_CONV) + 2 * n_block == 293
+    assert [d[1] for d in plain.describe()].count(_lib.UDP_OP_CONV) == kinds.count(_lib.UDP_OP_CONV) + 1
+    assert plain.macs_per_image() == prog.macs_per_image()
+    assert prog.activation_elems_per_image() == plain.activation_elems_per_image() - 2 * 256 * 64 * 48
+    cat = [d for d in prog.describe() if d[0] == "layer1.0.conv3"][0]
+    assert cat[4:6] == (128, 256)
     assert prog.macs_per_image() == 7670857728                                        # 7.671 GMAC
     ops = prog.ops_array()
     assert ops[len(ops) - 1].out_buf == _lib.UDP_BUF_OUTPUT and ops[len(ops) - 1].cout == 17

@@ -226,20 +226,33 @@ __device__ __forceinline__ void conv_ws_body(const ConvParams& p, const int tile
       if (c == 2) UDP_STAMP(11);
       if (c == 4) UDP_STAMP(13);
       // (at s == 0 the residual loads, issued behind the chunk-0 DMA, may stay in flight as well)
-      if (s == 0)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB + NR) : "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB) : "memory");
-      if (s == 0) UDP_STAMP(3);
-      __syncthreads();                                    // ... for every wave; nobody reads the other stage any more
-      if (s == 0) UDP_STAMP(4);
-      if (c == 1) UDP_STAMP(10);
-      if (c == 2) UDP_STAMP(12);
-      if (c == 4) UDP_STAMP(14);
+      bool refill = false;
+      if constexpr (STRIDE == 2) refill = p.sbuf && c > 0;
+      if (refill) {
+        // ONE stage buffer (stride-2 convs with several K chunks: their 4x input tile makes two stage buffers 110 KB,
+        // i.e. one workgroup -- four waves -- per CU; with one buffer two workgroups fit and hide each other's DMA):
+        // refill it once every wave has left chunk c - 1, wait for it (the A loads just issued are older), go on
+        __syncthreads();
+        stage(c, smem);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        sb = smem;
+      } else {
+        if (s == 0)
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB + NR) : "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB) : "memory");
+        if (s == 0) UDP_STAMP(3);
+        __syncthreads();                                    // ... for every wave; nobody reads the other stage any more
+        if (s == 0) UDP_STAMP(4);
+        if (c == 1) UDP_STAMP(10);
+        if (c == 2) UDP_STAMP(12);
+        if (c == 4) UDP_STAMP(14);
 #if !(UDP_WS_DBG & 4)
-      if (c + 1 < nchunks) stage(c + 1, smem + ((c + 1) & 1) * stage_bytes);
+        if (c + 1 < nchunks && !(STRIDE == 2 && p.sbuf)) stage(c + 1, smem + ((c + 1) & 1) * stage_bytes);
 #endif
-      sb = smem + (c & 1) * stage_bytes;
+        sb = smem + (c & 1) * stage_bytes;
+      }
     }
     // the cross term hi * Xlo: activations keep their lo plane scaled by 2^11 (storage format), so the weight side
     // carries 2^-11 -- four packed fp16 multiplies per fragment and step (exact unless the product goes subnormal,
@@ -476,7 +489,7 @@ static int describe_ws_pb(const ConvParams& p, int pb, int cp, size_t lds, Launc
   return 1;
 }
 struct WsTile {
-  int cp, pb, G, R, TW, wgs;
+  int cp, pb, G, R, TW, wgs, sbuf;
   size_t lds;
 };
 // Tile of a (cout pairs per workgroup, pixel blocks per wave) candidate; false if it cannot be built.
@@ -505,8 +518,15 @@ static bool ws_tile(const ConvParams& p, int ks, int stride, int cp, int pb, WsT
     while (npix(G, R) > MAXG * 64 && G > 1) --G;
     while (npix(G, R) > MAXG * 64 && R > 1) R = (R + 1) / 2;
     if (npix(G, R) > MAXG * 64) continue;
-    const int nstage = ceil_div(p.Cin, 32) > 1 ? 2 : 1;                         // stage buffers x (hi, lo) images
-    const size_t lds = (size_t)((npix(G, R) + 15) / 16) * 16 * ROWB * 2 * nstage;
+    int nstage = ceil_div(p.Cin, 32) > 1 ? 2 : 1;                               // stage buffers x (hi, lo) images
+    size_t lds = (size_t)((npix(G, R) + 15) / 16) * 16 * ROWB * 2 * nstage;
+    // stride 2: a second workgroup per CU is worth more than the second stage buffer (conv_ws_body, `refill`)
+    static const bool sbuf_ok = getenv("UDP_POSE_WS_SBUF") == nullptr || atoi(getenv("UDP_POSE_WS_SBUF")) != 0;
+    const bool sbuf = stride == 2 && nstage == 2 && lds > 80 * 1024 && lds / 2 <= 80 * 1024 && sbuf_ok;
+    if (sbuf) {
+      nstage = 1;
+      lds /= 2;
+    }
     if (lds > 160 * 1024) continue;
     // pixel blocks per wave the tile really needs (the halo limit may have shrunk it): the smallest instantiated
     // count that covers them, so no wave idles under masked blocks
@@ -527,6 +547,7 @@ static bool ws_tile(const ConvParams& p, int ks, int stride, int cp, int pb, WsT
       t->R = R;
       t->TW = TW;
       t->lds = lds;
+      t->sbuf = sbuf ? 1 : 0;
       t->wgs = tiles * (p.CoutPad / (cp * 32));
     }
   }
@@ -569,6 +590,7 @@ int describe_conv_ws(ConvParams p, int ks, int stride, Launch* out, bool grouped
   p.G = best.G;
   p.R = best.R;
   p.TW = best.TW;
+  p.sbuf = best.sbuf;
   p.IH = (p.R - 1) * stride + ks;
   p.IW = (p.TW - 1) * stride + ks;
   p.tiles_x = ceil_div(p.Wout, p.TW);
@@ -580,8 +602,8 @@ int describe_conv_ws(ConvParams p, int ks, int stride, Launch* out, bool grouped
   p.mTW = magic(p.TW);
   p.ntiles = ceil_div(p.N, p.G) * p.tiles_y * p.tiles_x;
   if (getenv("UDP_POSE_DEBUG_TILES"))
-    fprintf(stderr, "ws conv k%d s%d %dx%d C%d->%d: G=%d R=%d TW=%d CP=%d PB=%d lds=%zu wgs=%d\n", ks, stride, p.Hout, p.Wout, p.Cin,
-            p.Cout, p.G, p.R, p.TW, best.cp, best.pb, best.lds, best.wgs);
+    fprintf(stderr, "ws conv k%d s%d %dx%d C%d->%d: G=%d R=%d TW=%d CP=%d PB=%d lds=%zu%s wgs=%d\n", ks, stride, p.Hout, p.Wout, p.Cin,
+            p.Cout, p.G, p.R, p.TW, best.cp, best.pb, best.lds, best.sbuf ? " (one stage buffer)" : "", best.wgs);
   int rc = 1;
   if (ks == 3 && stride == 1) rc = describe_ws_pb<3, 1, false>(p, best.pb, best.cp, best.lds, out);
   if (ks == 3 && stride == 2) rc = describe_ws_pb<3, 2, false>(p, best.pb, best.cp, best.lds, out);

@@ -114,8 +114,13 @@ class HRNetProgram:
             b = (b - mean) * s + beta
         return w.to(torch.float32), b.to(torch.float32)
 
-    def _pack_conv(self, conv, bn, ws=False):
+    def _pack_conv(self, conv, bn, ws=False, plus=None):
         w, b = self._fold(conv, bn)
+        if plus is not None:                    # conv(x_a) + conv'(x_b) = one conv over [x_a | x_b]
+            w2, b2 = self._fold(*plus)
+            if w2.shape[0] != w.shape[0] or w2.shape[2:] != w.shape[2:]:
+                raise ValueError("%s + %s: different geometry" % (conv, plus[0]))
+            w, b = torch.cat([w, w2], dim=1), b + b2
         cout, cin, kh, kw = w.shape
         cout_pad = _round_up(cout, 32)
         wp = torch.zeros(kh * kw, cout_pad, cin, dtype=torch.float32)
@@ -137,18 +142,33 @@ class HRNetProgram:
         self._tensors.append(t)
         return t
 
-    def _conv(self, x, conv, bn, stride=1, relu=True, res=None, ups=(), to_output=False, group=0):
+    def _conv(self, x, conv, bn, stride=1, relu=True, res=None, ups=(), to_output=False, group=0, in_coff=None,
+              into=None, plus=None):
+        """One conv + folded BatchNorm (+ residual / upsampled addends, + ReLU).  ``in_coff``: read the ``cin`` channels
+        of ``x`` that start there (a channel-slice view); ``into = (tensor, coff)``: write the output into that slice of
+        an existing wider tensor; ``plus = (conv', bn')``: a second conv + BatchNorm of the same geometry whose input
+        channels FOLLOW this conv's in ``x`` and whose result is summed in -- one conv over the concatenated channels
+        with the weights side by side and the biases added."""
         ws = self.use_ws and not to_output and int(self.sd[conv + ".weight"].shape[2]) in (1, 3) and stride in (1, 2)
-        w_off, b_off, cout, cin, ks, cout_pad = self._pack_conv(conv, bn, ws)
-        if cin != x.c:
+        w_off, b_off, cout, cin, ks, cout_pad = self._pack_conv(conv, bn, ws, plus)
+        if cin != x.c and in_coff is None:
             raise ValueError("%s: weight expects %d input channels, tensor has %d" % (conv, cin, x.c))
         pad = ks // 2
         ho = (x.h + 2 * pad - ks) // stride + 1
         wo = (x.w + 2 * pad - ks) // stride + 1
-        out = None if to_output else self._new(cout, ho, wo)
-        self._ops.append(dict(kind=_lib.UDP_OP_CONV, ks=ks, stride=stride, relu=int(relu), cin=cin, cout=cout,
-                              cout_pad=cout_pad, hin=x.h, win=x.w, hout=ho, wout=wo, inp=x, out=out, res=res,
-                              ups=list(ups), w_off=w_off, b_off=b_off, name=conv, group=group, wfmt=int(ws), wexp=self._wexp))
+        out = None if to_output else (into[0] if into else self._new(cout, ho, wo))
+        op = dict(kind=_lib.UDP_OP_CONV, ks=ks, stride=stride, relu=int(relu), cin=cin, cout=cout,
+                  cout_pad=cout_pad, hin=x.h, win=x.w, hout=ho, wout=wo, inp=x, out=out, res=res,
+                  ups=list(ups), w_off=w_off, b_off=b_off, name=conv, group=group, wfmt=int(ws), wexp=self._wexp)
+        if in_coff is not None:
+            if in_coff + cin > x.c:
+                raise ValueError("%s: channels %d..%d of a %d-channel tensor" % (conv, in_coff, in_coff + cin, x.c))
+            op.update(in_coff=in_coff, in_pitch=x.c)
+        if into:
+            if (out.h, out.w) != (ho, wo) or into[1] + cout > out.c:
+                raise ValueError("%s: output slice does not fit its tensor" % conv)
+            op.update(out_coff=into[1], out_pitch=out.c)
+        self._ops.append(op)
         return out
 
     def _next_group(self):
@@ -223,8 +243,24 @@ class HRNetProgram:
         self._ops.append(dict(kind=_lib.UDP_OP_STEM, ks=3, stride=2, relu=1, cin=3, cout=64, cout_pad=64, hin=H,
                               win=W, hout=H // 2, wout=W // 2, inp=None, out=x, res=None, ups=[], w_off=w_off,
                               b_off=b_off, name="conv1"))
-        x = self._conv(x, "conv2", "bn2", stride=2)
-        for k in range(4):                                           # layer1 (:297, Bottleneck :80-100)
+        # The first Bottleneck's projection shortcut (pose_hrnet.py:87-98: out = relu(bn3(conv3(t)) + bn_d(conv_d(x))))
+        # is a second 1x1 conv of the same shape as conv3: with t and x side by side in one tensor the two are ONE
+        # 1x1 conv over the concatenated channels -- the 4*planes-channel shortcut map is never written nor read back.
+        # (UDP_POSE_NO_L1_CONCAT=1: the two convs and the residual read, for A/B)
+        p0 = "layer1.0"
+        concat = (os.environ.get("UDP_POSE_NO_L1_CONCAT") is None and (p0 + ".downsample.0.weight") in sd
+                  and tuple(sd[p0 + ".downsample.0.weight"].shape[1:]) == (64, 1, 1)
+                  and tuple(sd[p0 + ".conv3.weight"].shape[1:]) == (64, 1, 1)
+                  and tuple(sd[p0 + ".conv2.weight"].shape[:2]) == (64, 64))
+        if concat:
+            cat = self._new(128, H // 4, W // 4)                     # [conv2 output t | block input x]
+            self._conv(x, "conv2", "bn2", stride=2, into=(cat, 64))
+            a = self._conv(cat, p0 + ".conv1", p0 + ".bn1", in_coff=64)
+            self._conv(a, p0 + ".conv2", p0 + ".bn2", into=(cat, 0))
+            x = self._conv(cat, p0 + ".conv3", p0 + ".bn3", plus=(p0 + ".downsample.0", p0 + ".downsample.1"))
+        else:
+            x = self._conv(x, "conv2", "bn2", stride=2)
+        for k in range(1 if concat else 0, 4):                       # layer1 (:297, Bottleneck :80-100)
             p = "layer1.%d" % k
             a = self._conv(x, p + ".conv1", p + ".bn1")
             bt = self._conv(a, p + ".conv2", p + ".bn2")
