@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define UDP_POSE_ABI_VERSION 18
+#define UDP_POSE_ABI_VERSION 19
 
 enum udp_status {
   UDP_OK = 0,
@@ -117,7 +117,7 @@ typedef struct udp_conv_op {
                               (HRNet branches); lane 0 runs on the caller's stream */
   int32_t n_wait;          /* cross-lane dependencies: this op starts after ops wait_op[0..n_wait) */
   int32_t wait_op[UDP_MAX_WAIT];
-  int64_t w2_off, b2_off;  /* UDP_OP_BLOCK: the second conv's weights / bias in the blob */
+  int64_t w2_off, b2_off;  /* UDP_OP_BLOCK / chain_cout: the second conv's weights / bias in the blob */
   int32_t group;           /* != 0: consecutive UDP_OP_CONV ops with the same group id are independent of each
                               other (same-depth convs of different HRNet branches) and may share one launch */
   int32_t wfmt;            /* weight layout of a UDP_OP_CONV.  0: [tap][cout_pad][cin] in dtype (UDP_F16X2: per row the
@@ -145,6 +145,15 @@ typedef struct udp_conv_op {
   int32_t n_out2;
   int32_t out2_buf[2], out2_coff[2], out2_pitch[2];
   int32_t add2_buf[2], add2_coff[2], add2_pitch[2];
+  /* Chained 1x1 conv (udp_hrnet_* programs; chain_cout == 0: none).  A UDP_F16X2 1x1 stride-1 UDP_OP_CONV with wfmt 1,
+   * cin 64 | 128, cout a multiple of 32, a dense-or-sliced NHWC `out`, no up-sampled addends and no second outputs feeds
+   * its result -- the value AS STORED in `out` -- straight into a second 1x1 conv + bias (+ ReLU if chain_relu) of
+   * chain_cout (= 64) output channels, written densely to chain_buf: the Bottleneck chain of pose_hrnet.py:80-100
+   * (conv3 + bn3 + shortcut + ReLU of one block, conv1 + bn1 + ReLU of the next) in one launch, the 4 * planes-channel
+   * map written once and not read back.  The second conv's weights are fragment-major ([cout / 32 chunks][chain_cout / 32
+   * pairs], scaled by 2^chain_wexp) at w2_off, its fp32 bias [chain_cout] at b2_off.  Both results equal those of the
+   * two separate convs bit for bit. */
+  int32_t chain_cout, chain_buf, chain_relu, chain_wexp;
 } udp_conv_op;
 
 typedef struct udp_hrnet udp_hrnet; /* opaque */

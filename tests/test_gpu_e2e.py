@@ -239,6 +239,36 @@ def test_sub_batch_lanes_change_no_number(w32_gaussian, n, flip):
     assert torch.equal(out["1"], out["2"])
 
 
+@pytest.mark.parametrize("n", [3, 64])
+def test_layer1_chained_convs_equal_separate_convs(w32_gaussian, n):
+    """conv3 (+ shortcut + ReLU) of a layer1 Bottleneck and conv1 (+ ReLU) of the next one run as ONE launch in the
+    split-fp16 mode (udp_conv_op.chain_cout, conv_chain_kernel: the second conv's K chunks are the first conv's
+    accumulators, handed over in registers).  Every accumulator sees the MFMAs of the separate convs in the same order:
+    the heat-maps are those of the separate launches, bit for bit -- a ragged pixel count (3 crops x 2 = 18432 pixels,
+    not a multiple of the 128-pixel workgroup) and the bench batch."""
+    sd, _ = w32_gaussian
+    x = torch.from_numpy(synth.synth_crops(8, 256, 192, seed=83)).cuda().repeat((n + 7) // 8, 1, 1, 1)[:n].contiguous()
+    x += 0.01 * torch.randn(x.shape, device="cuda", generator=torch.Generator("cuda").manual_seed(n + 1))
+    out = {}
+    saved = os.environ.get("UDP_POSE_NO_L1_CHAIN")
+    try:
+        for chain in (True, False):
+            os.environ.pop("UDP_POSE_NO_L1_CHAIN", None)
+            if not chain:
+                os.environ["UDP_POSE_NO_L1_CHAIN"] = "1"
+            net = MODELS["pose_hrnet"](_cfg(synth.W32_EXTRA, 17, "gaussian"), is_train=False, dtype="f16x2")
+            net.load_state_dict(sd).to("cuda")
+            out[chain] = net.raw_forward(x, flip_test=True).clone()
+            assert sum(1 for o in net._compiled[(256, 192)][2].ops_array() if o.chain_cout) == (3 if chain else 0)
+            del net
+    finally:
+        os.environ.pop("UDP_POSE_NO_L1_CHAIN", None)
+        if saved is not None:
+            os.environ["UDP_POSE_NO_L1_CHAIN"] = saved
+    assert torch.isfinite(out[True]).all() and out[True].abs().max() > 0
+    assert torch.equal(out[True], out[False])
+
+
 def test_w32_bf16_mode_accuracy(golden_dir, w32_gaussian):
     """bf16 storage (fp32 accumulate) is REDUCED PRECISION and not a parity mode: this is a sanity bound on what it
     does to the (noise-like) reference heat-maps, far outside the 1e-3 / arg-max contract that the fp32 and

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libudp_pose_hip.so does not export %s" % name
     assert declared == set(_lib.EXPORTS)
-    assert lib.udp_abi_version() == _lib.ABI_VERSION == 18
+    assert lib.udp_abi_version() == _lib.ABI_VERSION == 19
 
 
 def test_argument_validation_without_gpu():
@@ -55,7 +55,7 @@ def test_taps_match_documented_opencv_rule():
     assert abs(float(t.sum()) - 1.0) < 1e-6
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f16x2"])
 def test_program_census_matches_survey(dtype, monkeypatch):
     sd = synth.synth_state_dict(synth.W32_EXTRA, 17, "gaussian", seed=0)
     monkeypatch.setenv("UDP_POSE_NO_L1_CONCAT", "1")
@@ -67,10 +67,19 @@ def test_program_census_matches_survey(dtype, monkeypatch):
     n_block = kinds.count(_lib.UDP_OP_BLOCK)       # bf16: the 32 BasicBlocks of the 32-channel branch are one launch each
     assert n_block == (32 if dtype == "bf16" else 0)
     # 294 convs; layer1.0's conv3 and projection shortcut are ONE conv over the concatenated channels
-    assert kinds.count(_lib.UDP_OP_STEM) + kinds.count(_lib.UDP_OP_CONV) + 2 * n_block == 293
+    # split fp16: conv3 of layer1.k and conv1 of layer1.k+1 are one chained launch (udp_conv_op.chain_cout), k = 0..2
+    chained = sum(1 for o in prog.ops_array() if o.chain_cout)
+    assert chained == (3 if dtype == "f16x2" else 0)
+    assert kinds.count(_lib.UDP_OP_STEM) + kinds.count(_lib.UDP_OP_CONV) + 2 * n_block + chained == 293
     assert [d[1] for d in plain.describe()].count(_lib.UDP_OP_CONV) == kinds.count(_lib.UDP_OP_CONV) + 1
     assert plain.macs_per_image() == prog.macs_per_image()
+    # the shortcut map is neither written nor read back; a chained conv does not read the 256-channel map again
     assert prog.activation_elems_per_image() == plain.activation_elems_per_image() - 2 * 256 * 64 * 48
+    monkeypatch.setenv("UDP_POSE_NO_L1_CHAIN", "1")
+    unchained = hrnet_plan.HRNetProgram(sd, synth.W32_EXTRA, 256, 192, dtype)
+    assert not any(o.chain_cout for o in unchained.ops_array())
+    assert unchained.macs_per_image() == prog.macs_per_image()
+    assert prog.activation_elems_per_image() == unchained.activation_elems_per_image() - chained * 256 * 64 * 48
     cat = [d for d in prog.describe() if d[0] == "layer1.0.conv3"][0]
     assert cat[4:6] == (128, 256)
     assert prog.macs_per_image() == 7670857728                                        # 7.671 GMAC

@@ -16,7 +16,7 @@ DTYPES = {"f32": UDP_F32, "bf16": UDP_BF16, "f16x2": UDP_F16X2}
 UDP_OP_STEM, UDP_OP_CONV, UDP_OP_FUSE, UDP_OP_STEM7, UDP_OP_MAXPOOL, UDP_OP_BILINEAR = 0, 1, 2, 3, 4, 5
 UDP_OP_PSA_POOL, UDP_OP_PSA_MLP, UDP_OP_PSA_SCALE, UDP_OP_PSA_SP, UDP_OP_BLOCK = 6, 7, 8, 9, 10
 UDP_BUF_NONE, UDP_BUF_OUTPUT = -1, -2
-ABI_VERSION = 18
+ABI_VERSION = 19
 MAX_LANES, MAX_WAIT = 4, 8
 
 
@@ -57,6 +57,7 @@ class ConvOp(C.Structure):
         ("group", C.c_int32), ("wfmt", C.c_int32), ("wexp", C.c_int32), ("in_stuff2", C.c_int32),
         ("n_out2", C.c_int32), ("out2_buf", C.c_int32 * 2), ("out2_coff", C.c_int32 * 2), ("out2_pitch", C.c_int32 * 2),
         ("add2_buf", C.c_int32 * 2), ("add2_coff", C.c_int32 * 2), ("add2_pitch", C.c_int32 * 2),
+        ("chain_cout", C.c_int32), ("chain_buf", C.c_int32), ("chain_relu", C.c_int32), ("chain_wexp", C.c_int32),
     ]
 
 

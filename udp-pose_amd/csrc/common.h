@@ -128,6 +128,7 @@ struct Launch {
 // conv_ws.hip: the weight-stationary split-fp16 convs (tile choice + kernel of one conv; merged launch of 2..4)
 int describe_conv_ws(ConvParams p, int ks, int stride, Launch* out, bool grouped = false);
 int describe_ws_multi(const Launch* members, int n, ConvMulti* m, Launch* out);
+int describe_conv_chain(ConvParams p, Launch* out);   // two 1x1 convs chained through registers (udp_conv_op.chain_cout)
 void ws_set_fill_wgs(long wgs);                       // workgroups a conv launched on its own should reach (tile choice)
 int ws_set_stamps(unsigned long long* dev_buf);      // diagnostic builds (-DUDP_STAMPS) only
 int conv_h2_overflow(hipStream_t s, int reset, int* flag);       // conv.hip / conv_ws.hip / psa.hip: their g_h2_overflow

@@ -81,12 +81,22 @@ __device__ __forceinline__ void conv_ws_body(const ConvParams& p, const int tile
   const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<void*>(p.wgt), 0, (unsigned)TAPS * nchunks * npairs * 4096u, 0x00020000);
   // (no `out`: second outputs only, udp_conv_op.n_out2 -- a zero-length descriptor drops the stores)
+#if UDP_WS_DBG & 32      // (timing-only build: the one-chunk convs store nothing)
+  const bool dbg_nost = nchunks == 1;
+#else
+  constexpr bool dbg_nost = false;
+#endif
+#if UDP_WS_DBG & 64      // (timing-only build: the one-chunk convs read no residual)
+  const bool dbg_nores = nchunks == 1;
+#else
+  constexpr bool dbg_nores = false;
+#endif
   const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(
-      p.out, 0, !p.out ? 0 : NCHW ? out_pix * p.Cout * 4 : out_pix * outpb, 0x00020000);
+      p.out, 0, (!p.out || dbg_nost) ? 0 : NCHW ? out_pix * p.Cout * 4 : out_pix * outpb, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_bias = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.bias), 0, (unsigned)p.CoutPad * 4u, 0x00020000);
   const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<void*>(p.res), 0, p.res ? out_pix * respb : 0, 0x00020000);
+      const_cast<void*>(p.res), 0, (p.res && !dbg_nores) ? out_pix * respb : 0, 0x00020000);
 
   const int cwave = (cby * CP + cp) * 32;   // first cout of the wave's pair of blocks
   const int cbase = cwave + 8 * kg;                // the lane's 8 consecutive output channels
@@ -798,6 +808,273 @@ int ws_set_stamps(unsigned long long* dev_buf) {
 // the weight-stationary kernels' stamps alone (libudp_pose_hip_stamps_ws.so links the product conv.o)
 extern "C" int udp_debug_set_stamps_ws(unsigned long long* dev_buf) { return ws_set_stamps(dev_buf); }
 #endif
+
+// ---------------------------------------------------------------------------------------------------------------
+// Two 1x1 convs chained through registers (udp_conv_op.chain_cout; the layer1 Bottlenecks, pose_hrnet.py:80-100: conv3
+// + bn3 + shortcut + ReLU of one block, conv1 + bn1 + ReLU of the next):
+//     Y = act(W . X + b [+ R])            Cin = 32 * NCH  ->  Cout = 32 * NP      (written to `out`)
+//     Z = act2(W2 . Y_as_stored + b2)     Cout            ->  Cout2 = 64          (written to `chain`)
+// Both run at the memory roofline on their own; chained, the 4 * planes-channel map Y is written once and not read back
+// (1.41 -> 1.01 GB per pair at 128 images).  PIXEL-stationary: a wave owns 16 * PB pixels, keeps their X fragments in
+// registers and walks the cout pairs of the first conv; the accumulators of pair p -- lane (kg, li) holds couts
+// 32p + 8kg .. + 7 of pixel li, the fragment-major row order (udp_conv_op.wfmt) -- are, after the epilogue and the
+// split into (hi, lo), exactly the B fragment of K chunk p of the second conv: no LDS, no barrier, the waves of a
+// workgroup only share the weight fragments in L1 / L2.  Every accumulator sees the MFMAs of the separate convs in
+// the same order (chunk by chunk: hi * Xhi, lo * Xhi, hi * 2^-11 * Xlo), so Y and Z are theirs bit for bit.
+// Chain fields ride in ConvParams members the 1x1 conv does not use (no up-sampled addends here): wgt2 / bias2 = W2 /
+// b2, up[0] = Z, up_shift[0..2] = Cout2, wexp2, act2.
+// LDSW: the weights of both convs (and the biases) live in LDS -- 128 KiB + 1.25 KiB for Cin = 64, staged once by a
+// persistent 8-wave workgroup per CU whose waves then walk the pixel groups: the vector-memory queue carries only what
+// comes from / goes to HBM (with the fragments streamed from L2 they are 128 of the 224 vector-memory instructions of a
+// wave, each 16 cycles of the CU's address unit, and every one of them queues behind the residual loads).
+template <int NCH, int PB, int RD, bool LDSW>
+__global__ __launch_bounds__(LDSW ? 512 : 256) __attribute__((amdgpu_waves_per_eu(2))) void conv_chain_kernel(const ConvParams p) {
+  using T = H2;
+  constexpr int ESZ = 2, NB = 2, Q = 2;          // Q: cout pairs of the second conv (Cout2 = 64)
+  constexpr int NWAVES = LDSW ? 8 : 4;
+  constexpr int AD = LDSW ? 2 : 3;               // fragment ring: from L2 the step after next is in flight, from LDS the next one
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, kg = lane >> 4;
+  const unsigned npix = (unsigned)p.N * p.Hout * p.Wout;
+  constexpr int NP = 8;                          // cout pairs of the first conv (Cout = 256) = K chunks of the second.  A constant:
+  // the pairs are straight-line code -- a pair under `if (k < NP)` makes hipcc drain every load at the join (vmcnt(0)), and
+  // with it every prefetch across pairs
+  const int cout2 = p.up_shift[0];
+  const unsigned inpb = (unsigned)p.in_pitch * ESZ * 2, outpb = (unsigned)p.out_pitch * ESZ * 2, respb = (unsigned)p.res_pitch * ESZ * 2;
+  const unsigned zpb = (unsigned)cout2 * ESZ * 2;
+  const unsigned in_lo = (unsigned)p.in_pitch * ESZ, out_lo = (unsigned)p.out_pitch * ESZ, res_lo = (unsigned)p.res_pitch * ESZ;
+  const unsigned z_lo = (unsigned)cout2 * ESZ;
+  const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.in), 0, (p.sbuf & 8) ? 0 : npix * inpb, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt), 0, (p.sbuf & 1) ? 0 : (unsigned)NCH * NP * 4096u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wgt2), 0, (p.sbuf & 1) ? 0 : (unsigned)NP * Q * 4096u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_bias = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias), 0, (unsigned)p.CoutPad * 4u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_bias2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias2), 0, (unsigned)cout2 * 4u, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res), 0, (p.res && !(p.sbuf & 4)) ? npix * respb : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (p.sbuf & 2) ? 0 : npix * outpb, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.up[0]), 0, (p.sbuf & 2) ? 0 : npix * zpb, 0x00020000);
+  const float winv = __builtin_ldexpf(1.f, -p.wexp), winv2 = __builtin_ldexpf(1.f, -p.up_shift[1]);
+  const unsigned wvoff = (unsigned)lane * 16u;
+
+  constexpr unsigned kW1 = (unsigned)NCH * 8 * 4096u, kBias = kW1 + 8u * Q * 4096u;     // LDS offsets: second conv's weights, biases
+  if constexpr (LDSW) {
+    for (unsigned blk = wave; blk < kBias / 1024u; blk += NWAVES) {
+      const bool first = blk * 1024u < kW1;
+      blds16(first ? r_w : r_w2, (first ? blk * 1024u : blk * 1024u - kW1) + wvoff, smem + blk * 1024u);
+    }
+    float* sbias = reinterpret_cast<float*>(smem + kBias);
+    if (threadIdx.x < 256 + 64) sbias[threadIdx.x] = threadIdx.x < 256 ? p.bias[threadIdx.x] : p.bias2[threadIdx.x - 256];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  const unsigned ngroups = (npix + PB * 16 - 1) / (PB * 16);
+  for (unsigned grp = (unsigned)blockIdx.x * NWAVES + wave; grp < ngroups; grp += LDSW ? gridDim.x * NWAVES : ngroups) {
+  // (per-lane constants re-derived inside the loop: hoisted out, the offsets of all eight pairs live across it -- spills)
+  unsigned wv = wvoff;
+  int kgl = kg;
+  if constexpr (LDSW) {
+    asm volatile("" : "+v"(wv));
+    asm volatile("" : "+v"(kgl));
+  }
+  unsigned pix[PB];
+  bool ok[PB];
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    pix[i] = grp * (PB * 16) + i * 16 + li;
+    ok[i] = pix[i] < npix;
+  }
+  // X fragments of the wave's pixels: lane (kg, li) holds channels 32c + 8kg .. + 7 of pixel li (hi and lo planes)
+  f16x8 xh[PB][NCH], xl[PB][NCH];
+#pragma unroll
+  for (int i = 0; i < PB; ++i)
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const unsigned off = ok[i] ? pix[i] * inpb + (unsigned)(p.in_coff + 32 * c + 8 * kgl) * ESZ : kOobOff;
+      xh[i][c] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r_in, off, 0, 0));
+      xl[i][c] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(r_in, off + in_lo, 0, 0));
+    }
+  // weight fragments: steps of one cout pair pr = NCH chunks of the first conv, then Q pairs of the second; the
+  // fragments of the step after next stream in from L2 (ring of three, as in conv_ws_body)
+  constexpr int S = NCH + Q;
+  f16x8 ah[AD][NB], al[AD][NB];
+  auto load_a = [&](int pr, int st, f16x8 (&h)[NB], f16x8 (&l)[NB]) __attribute__((always_inline)) {
+    const bool first = st < NCH;
+    const unsigned soff = first ? (unsigned)(st * NP + pr) * 4096u : (unsigned)(pr * Q + (st - NCH)) * 4096u;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      if constexpr (LDSW) {
+        const unsigned char* q = smem + (first ? 0u : kW1) + soff + wv + 2048u * nb;
+        h[nb] = *reinterpret_cast<const f16x8*>(q);
+        l[nb] = *reinterpret_cast<const f16x8*>(q + 1024);
+      } else {
+        h[nb] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(first ? r_w : r_w2, wv + 2048u * nb, soff, 0));
+        l[nb] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(first ? r_w : r_w2, wv + 2048u * nb + 1024u, soff, 0));
+      }
+    }
+  };
+  // residual of the pair RD - 1 ahead in flight (vector-memory operations complete in issue order: the weight fragments
+  // requested behind a residual load arrive with it, so the distance also bounds how long a fragment can be held up)
+  ResH2<NB> rres[RD][PB];
+  auto load_res = [&](int pr, ResH2<NB> (&r)[PB]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < PB; ++i)
+      load_res_h2(r[i], r_res, ok[i] ? pix[i] * respb + (unsigned)(p.res_coff + 32 * pr + 8 * kgl) * ESZ : kOobOff, res_lo);
+  };
+#pragma unroll
+  for (int k = 0; k < RD - 1; ++k) load_res(k, rres[k]);
+  load_a(0, 0, ah[0], al[0]);
+  if constexpr (AD > 2) load_a(0, 1, ah[1], al[1]);
+
+  f32x4 acc2[PB][Q][NB];
+#pragma unroll
+  for (int i = 0; i < PB; ++i)
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc2[i][q][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto mfma3 = [&](f32x4 (&acc)[NB], const f16x8 (&h)[NB], const f16x8 (&l)[NB], const f16x8 (&a2)[NB], const f16x8 bh, const f16x8 bl)
+      __attribute__((always_inline)) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(h[nb], bh, acc[nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(l[nb], bh, acc[nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[nb], bl, acc[nb], 0, 0, 0);
+      };
+
+  // one cout pair of the first conv = one K chunk of the second; BUF0 = ring slot of its first step (S steps per pair)
+  auto pair_body = [&](auto KC) __attribute__((always_inline)) {
+    constexpr int pr = decltype(KC)::value, BUF0 = (pr * S) % AD, SIDE = pr % RD;
+    if constexpr (pr + RD - 1 < NP) load_res(pr + RD - 1, rres[(SIDE + RD - 1) % RD]);
+    f32x4 bias[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      if constexpr (LDSW)
+        bias[nb] = *reinterpret_cast<const f32x4*>(smem + kBias + (unsigned)(32 * pr + 8 * kgl + 4 * nb) * 4u);
+      else
+        bias[nb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_bias, (unsigned)(32 * pr + 8 * kgl + 4 * nb) * 4u, 0, 0));
+    }
+    f32x4 acc[PB][NB];
+#pragma unroll
+    for (int i = 0; i < PB; ++i)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[i][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f16x8 yh[PB], yl[PB];
+#pragma unroll
+    for (int st = 0; st < S; ++st) {
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int buf = (BUF0 + st) % AD;
+      {   // fragments of the step AD - 1 ahead (unconditional: past the end the last step's again)
+        int npr = pr, nst = st + AD - 1;
+        if (nst >= S) {
+          nst -= S;
+          npr = pr + 1 < NP ? pr + 1 : pr;
+          if (pr + 1 >= NP) nst = S - 1;
+        }
+        load_a(npr, nst, ah[(buf + AD - 1) % AD], al[(buf + AD - 1) % AD]);
+      }
+      f16x8 a2[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) a2[nb] = ah[buf][nb] * (_Float16)0x1p-11f;
+      if (st < NCH) {
+#pragma unroll
+        for (int i = 0; i < PB; ++i) mfma3(acc[i], ah[buf], al[buf], a2, xh[i][st], xl[i][st]);
+        if (st == NCH - 1) {
+          // epilogue of the first conv for this pair: conv_ws_body's, value by value
+          const int cbase = 32 * pr + 8 * kgl;
+#pragma unroll
+          for (int i = 0; i < PB; ++i) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) acc[i][nb][q] = __builtin_fmaf(acc[i][nb][q], winv, bias[nb][q]);
+            add_res_h2(acc[i], rres[SIDE][i]);
+            if (p.relu) {
+#pragma unroll
+              for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[i][nb][q] = acc[i][nb][q] > 0.f ? acc[i][nb][q] : 0.f;
+            }
+            h2_split8(acc[i][0], acc[i][1], yh[i], yl[i]);
+            const unsigned ooff = ok[i] ? pix[i] * outpb + (unsigned)(p.out_coff + cbase) * ESZ : kOobOff;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, yh[i]), r_out, ooff, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, yl[i]), r_out, ooff + out_lo, 0, 0);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < PB; ++i) mfma3(acc2[i][st - NCH], ah[buf], al[buf], a2, yh[i], yl[i]);
+      }
+    }
+  };
+  // S steps per pair over a ring of three: the ring slot of a pair's first step cycles with period 3 / gcd(S, 3)
+  pair_body(std::integral_constant<int, 0>{});
+  pair_body(std::integral_constant<int, 1>{});
+  pair_body(std::integral_constant<int, 2>{});
+  pair_body(std::integral_constant<int, 3>{});
+  pair_body(std::integral_constant<int, 4>{});
+  pair_body(std::integral_constant<int, 5>{});
+  pair_body(std::integral_constant<int, 6>{});
+  pair_body(std::integral_constant<int, 7>{});
+  // epilogue of the second conv
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int cbase = 32 * q + 8 * kgl;
+    f32x4 b2[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      if constexpr (LDSW)
+        b2[nb] = *reinterpret_cast<const f32x4*>(smem + kBias + 1024u + (unsigned)(cbase + 4 * nb) * 4u);
+      else
+        b2[nb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_bias2, (unsigned)(cbase + 4 * nb) * 4u, 0, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      f32x4 v[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          v[nb][k] = __builtin_fmaf(acc2[i][q][nb][k], winv2, b2[nb][k]);
+          if (p.up_shift[2]) v[nb][k] = v[nb][k] > 0.f ? v[nb][k] : 0.f;
+        }
+      store_vec_buf<T, NB>(r_z, ok[i] ? pix[i] * zpb + (unsigned)cbase * ESZ : kOobOff, z_lo, v);
+    }
+  }
+  }   // pixel groups
+}
+
+int describe_conv_chain(ConvParams p, Launch* out) {
+  const int cout2 = p.up_shift[0];
+  if (p.Cin % 32 || (p.Cin != 64 && p.Cin != 128) || p.CoutPad != p.Cout || p.Cout != 256 || cout2 != 64 || p.nup ||
+      p.nout2 || p.out_nchw_f32 || !p.out || !p.up[0] || !p.wgt2 || !p.bias2 || p.Hin != p.Hout || p.Win != p.Wout)
+    return fail(UDP_ERR_UNSUPPORTED, "chained 1x1 convs: C%d -> %d -> %d (64 | 128 -> 256 -> 64, dense NHWC outputs)", p.Cin, p.Cout, cout2);
+  // A/B (UDP_POSE_CHAIN_VAR): 0 = weights in LDS where they fit (Cin = 64), 1 = streamed from L2 everywhere
+  static const int var = getenv("UDP_POSE_CHAIN_VAR") ? atoi(getenv("UDP_POSE_CHAIN_VAR")) : 0;
+  constexpr int PB = 2;
+  const long npix = (long)p.N * p.Hout * p.Wout;
+  if (npix * (long)std::max(std::max(p.in_pitch, p.out_pitch), p.res_pitch) * 4 >= (1L << 31))
+    return fail(UDP_ERR_UNSUPPORTED, "chained 1x1 convs: tensor beyond the 2 GiB buffer-descriptor range");
+  const long groups = (npix + PB * 16 - 1) / (PB * 16);
+  out->lds = 0;
+  if (p.Cin == 64 && var == 0) {
+    out->fn = reinterpret_cast<const void*>(&conv_chain_kernel<2, PB, 3, true>);
+    out->lds = (2 * 8 + 8 * 2) * 4096 + 1280;
+    out->grid = dim3((unsigned)std::min<long>(256, (groups + 7) / 8));
+    out->block = dim3(512);
+    UDP_HIP_CHECK(hipFuncSetAttribute(out->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)out->lds));
+  } else {
+    out->fn = p.Cin == 64 ? reinterpret_cast<const void*>(&conv_chain_kernel<2, PB, 3, false>) : reinterpret_cast<const void*>(&conv_chain_kernel<4, PB, 2, false>);
+    out->grid = dim3((unsigned)((groups + 3) / 4));
+    out->block = dim3(256);
+  }
+  out->groupable = 0;
+  out->p = p;
+  out->p.sbuf = getenv("UDP_POSE_CHAIN_DBG") ? atoi(getenv("UDP_POSE_CHAIN_DBG")) : 0;   // timing-only ablations (results WRONG): 1 no weights, 2 no stores, 4 no residual, 8 no X
+  return UDP_OK;
+}
 
 int conv_ws_h2_overflow(hipStream_t s, int reset, int* flag) { return h2_overflow_fetch(s, reset, flag); }
 

@@ -156,6 +156,17 @@ static int validate_op(const udp_hrnet* h, const udp_conv_op& o, int idx) {
       return fail(UDP_ERR_ARG, "op %d: up_shift %d does not divide %dx%d", idx, s, o.hout, o.wout);
     if (!buf_ok(o.up_buf[u], (int64_t)(o.hout >> s) * (o.wout >> s) * o.cout)) return fail(UDP_ERR_ARG, "op %d: up_buf %d", idx, u);
   }
+  if (o.chain_cout) {
+    if (o.kind != UDP_OP_CONV || o.wfmt != 1 || h->dtype != UDP_F16X2 || o.ks != 1 || o.stride != 1 || o.group || o.n_up || o.n_out2 ||
+        o.out_buf < 0 || (o.cin != 64 && o.cin != 128) || o.cout % 32 || o.cout_pad != o.cout || o.chain_cout != 64)
+      return fail(UDP_ERR_UNSUPPORTED, "op %d: a chained conv needs an ungrouped split-fp16 1x1 conv (wfmt 1), 64 | 128 -> 32k channels, and 64 chained outputs", idx);
+    if (!buf_ok(o.chain_buf, (int64_t)o.hout * o.wout * o.chain_cout) || o.chain_buf == o.out_buf || o.chain_buf == o.in_buf || o.chain_buf == o.res_buf)
+      return fail(UDP_ERR_ARG, "op %d: chain_buf %d missing, too small or aliased", idx, o.chain_buf);
+    const size_t w2bytes = (size_t)(o.cout / 32) * (o.chain_cout / 32) * 4096;
+    if (o.w2_off < 0 || (size_t)o.w2_off + w2bytes > h->weights_bytes || (o.w2_off & 15) || o.b2_off < 0 ||
+        (size_t)o.b2_off + (size_t)o.chain_cout * 4 > h->weights_bytes || (o.b2_off & 15) || o.chain_wexp < -40 || o.chain_wexp > 40)
+      return fail(UDP_ERR_ARG, "op %d: chained conv: weight / bias range outside the blob or misaligned", idx);
+  }
   if (o.n_out2 < 0 || o.n_out2 > 2) return fail(UDP_ERR_ARG, "op %d: n_out2", idx);
   if (o.n_out2 && (o.kind != UDP_OP_CONV || o.wfmt != 1 || h->dtype != UDP_F16X2 || o.out_buf == UDP_BUF_OUTPUT || o.cout % 8 || o.ks != 3 || o.stride != 1 || o.group))
     return fail(UDP_ERR_UNSUPPORTED, "op %d: second outputs need an ungrouped 3x3 stride-1 split-fp16 conv with fragment-major weights, an NHWC output and cout %% 8 == 0", idx);
@@ -220,6 +231,7 @@ extern "C" int udp_hrnet_create(const udp_conv_op* ops, int n_ops, const int64_t
     if (ops[i].kind == UDP_OP_STEM || ops[i].kind == UDP_OP_STEM7 || ops[i].kind == UDP_OP_CONV)
       h->flops += 2.0 * ops[i].ks * ops[i].ks * ops[i].cin * ops[i].cout * ops[i].hout * ops[i].wout;
     if (ops[i].kind == UDP_OP_BLOCK) h->flops += 2 * 2.0 * 9 * 32 * 32 * ops[i].hout * ops[i].wout;
+    if (ops[i].kind == UDP_OP_CONV && ops[i].chain_cout) h->flops += 2.0 * ops[i].cout * ops[i].chain_cout * ops[i].hout * ops[i].wout;
     h->ops.push_back(ops[i]);
   }
   if (!has_out || (h->ops[0].kind != UDP_OP_STEM && h->ops[0].kind != UDP_OP_STEM7) || h->ops[0].lane != 0 || h->ops.back().lane != 0 ||
@@ -333,6 +345,14 @@ static int describe_all(const udp_hrnet* h, const float* in, int n, int flip, ch
       p.wgt = h->weights + o.w_off;
       p.bias = reinterpret_cast<const float*>(h->weights + o.b_off);
     }
+    if (o.kind == UDP_OP_CONV && o.chain_cout) {     // conv_chain_kernel's use of the addend fields (validate_op: n_up == 0)
+      p.wgt2 = h->weights + o.w2_off;
+      p.bias2 = reinterpret_cast<const float*>(h->weights + o.b2_off);
+      p.up[0] = buf(o.chain_buf);
+      p.up_shift[0] = o.chain_cout;
+      p.up_shift[1] = o.chain_wexp;
+      p.up_shift[2] = o.chain_relu;
+    }
     if (o.kind == UDP_OP_BLOCK) {
       p.wgt = h->weights + o.w_off;
       p.bias = reinterpret_cast<const float*>(h->weights + o.b_off);
@@ -355,6 +375,10 @@ static int describe_all(const udp_hrnet* h, const float* in, int n, int flip, ch
       case UDP_OP_MAXPOOL: rc = describe_maxpool(p, h->dtype, &ls[i]); break;
       case UDP_OP_BILINEAR: rc = describe_bilinear(p, h->dtype, &ls[i]); break;
       default:
+        if (o.chain_cout) {
+          rc = describe_conv_chain(p, &ls[i]);
+          break;
+        }
         rc = o.group != 0 && getenv("UDP_POSE_NO_GROUPS") == nullptr ? describe_conv_grouped(p, h->dtype, o.ks, o.stride, &ls[i]) : 1;
         if (rc == 1) rc = describe_conv(p, h->dtype, o.ks, o.stride, &ls[i]);
     }
@@ -706,6 +730,7 @@ static int conv2d_params(const udp_conv_op* o, int dtype, int n, const void* in,
   p.CoutPad = o->cout_pad;
   p.relu = o->relu;
   if (o->n_out2) return fail(UDP_ERR_UNSUPPORTED, "udp_conv2d_fused: second outputs (n_out2) exist in udp_hrnet programs only");
+  if (o->chain_cout) return fail(UDP_ERR_UNSUPPORTED, "udp_conv2d_fused: chained convs (chain_cout) exist in udp_hrnet programs only");
   p.wfmt = o->wfmt;
   p.wexp = o->wexp;
   p.in_stuff2 = o->in_stuff2 ? 1 : 0;

@@ -143,12 +143,13 @@ class HRNetProgram:
         return t
 
     def _conv(self, x, conv, bn, stride=1, relu=True, res=None, ups=(), to_output=False, group=0, in_coff=None,
-              into=None, plus=None):
+              into=None, plus=None, chain=None):
         """One conv + folded BatchNorm (+ residual / upsampled addends, + ReLU).  ``in_coff``: read the ``cin`` channels
         of ``x`` that start there (a channel-slice view); ``into = (tensor, coff)``: write the output into that slice of
         an existing wider tensor; ``plus = (conv', bn')``: a second conv + BatchNorm of the same geometry whose input
         channels FOLLOW this conv's in ``x`` and whose result is summed in -- one conv over the concatenated channels
-        with the weights side by side and the biases added."""
+        with the weights side by side and the biases added; ``chain = (conv'', bn'')``: a 1x1 conv + BatchNorm + ReLU
+        applied to this conv's result in the same launch (udp_conv_op.chain_cout) -- returns ``(out, chained out)``."""
         ws = self.use_ws and not to_output and int(self.sd[conv + ".weight"].shape[2]) in (1, 3) and stride in (1, 2)
         w_off, b_off, cout, cin, ks, cout_pad = self._pack_conv(conv, bn, ws, plus)
         if cin != x.c and in_coff is None:
@@ -168,8 +169,18 @@ class HRNetProgram:
             if (out.h, out.w) != (ho, wo) or into[1] + cout > out.c:
                 raise ValueError("%s: output slice does not fit its tensor" % conv)
             op.update(out_coff=into[1], out_pitch=out.c)
+        if chain is not None:
+            from .f16x2 import pack_weights_ws
+            w2, b2 = self._fold(*chain)
+            c2 = int(w2.shape[0])
+            if not ws or ks != 1 or tuple(w2.shape[1:]) != (cout, 1, 1) or cout_pad != cout or c2 % 32:
+                raise ValueError("%s -> %s: not a chain of split-fp16 1x1 convs" % (conv, chain[0]))
+            packed, wexp2 = pack_weights_ws(w2.reshape(1, c2, cout))
+            z = self._new(c2, ho, wo)
+            op.update(chain_out=z, chain_cout=c2, chain_relu=1, chain_wexp=wexp2, w2_off=self._put(packed.numpy().tobytes()),
+                      b2_off=self._put(b2.numpy().tobytes()), chain_name=chain[0])
         self._ops.append(op)
-        return out
+        return (out, op["chain_out"]) if chain is not None else out
 
     def _next_group(self):
         self._groups += 1
@@ -252,22 +263,35 @@ class HRNetProgram:
                   and tuple(sd[p0 + ".downsample.0.weight"].shape[1:]) == (64, 1, 1)
                   and tuple(sd[p0 + ".conv3.weight"].shape[1:]) == (64, 1, 1)
                   and tuple(sd[p0 + ".conv2.weight"].shape[:2]) == (64, 64))
+        # conv3 (+ shortcut + ReLU) of a Bottleneck and conv1 (+ ReLU) of the next one are both 1x1: chained in one launch
+        # (udp_conv_op.chain_cout) the 256-channel map between them is written once and not read back.  Split-fp16 storage
+        # on the weight-stationary kernels only.  (UDP_POSE_NO_L1_CHAIN=1: separate launches, for A/B)
+        def nxt(k):
+            q = "layer1.%d" % (k + 1)
+            ok = (self.use_ws and os.environ.get("UDP_POSE_NO_L1_CHAIN") is None and k + 1 < 4
+                  and (q + ".downsample.0.weight") not in sd and tuple(sd[q + ".conv1.weight"].shape) == (64, 256, 1, 1)
+                  and tuple(sd["layer1.%d.conv3.weight" % k].shape) == (256, 64, 1, 1))
+            return (q + ".conv1", q + ".bn1") if ok else None
+        a = None                                                     # conv1 output of the block, when chained in
         if concat:
             cat = self._new(128, H // 4, W // 4)                     # [conv2 output t | block input x]
             self._conv(x, "conv2", "bn2", stride=2, into=(cat, 64))
             a = self._conv(cat, p0 + ".conv1", p0 + ".bn1", in_coff=64)
             self._conv(a, p0 + ".conv2", p0 + ".bn2", into=(cat, 0))
-            x = self._conv(cat, p0 + ".conv3", p0 + ".bn3", plus=(p0 + ".downsample.0", p0 + ".downsample.1"))
+            x = self._conv(cat, p0 + ".conv3", p0 + ".bn3", plus=(p0 + ".downsample.0", p0 + ".downsample.1"), chain=nxt(0))
+            x, a = x if isinstance(x, tuple) else (x, None)
         else:
             x = self._conv(x, "conv2", "bn2", stride=2)
         for k in range(1 if concat else 0, 4):                       # layer1 (:297, Bottleneck :80-100)
             p = "layer1.%d" % k
-            a = self._conv(x, p + ".conv1", p + ".bn1")
+            if a is None:
+                a = self._conv(x, p + ".conv1", p + ".bn1")
             bt = self._conv(a, p + ".conv2", p + ".bn2")
             r = x
             if (p + ".downsample.0.weight") in sd:
                 r = self._conv(x, p + ".downsample.0", p + ".downsample.1", relu=False)
-            x = self._conv(bt, p + ".conv3", p + ".bn3", res=r)
+            x = self._conv(bt, p + ".conv3", p + ".bn3", res=r, chain=nxt(k))
+            x, a = x if isinstance(x, tuple) else (x, None)
         ys = [x]
         for st in (2, 3, 4):
             cfg = self.extra["STAGE%d" % st]
@@ -390,7 +414,7 @@ class HRNetProgram:
                 if op["out"].id in producer:
                     readers.setdefault(op["out"].id, []).append(producer[op["out"].id])   # earlier slice writers
                 producer[op["out"].id] = idx
-            for t, _ in op.get("out2", []):
+            for t in [t for t, _ in op.get("out2", [])] + ([op["chain_out"]] if op.get("chain_out") is not None else []):
                 producer[t.id] = idx
             for t in reads_of(op):
                 readers.setdefault(t.id, []).append(idx)
@@ -408,7 +432,8 @@ class HRNetProgram:
             if out is not None and out.id in phys:
                 deps.add(producer[out.id])      # later slice of a concat buffer: ordered after its other writers
                 out = None
-            for out in ([out] if out is not None else []) + [t for t, _ in op.get("out2", [])]:
+            for out in (([out] if out is not None else []) + [t for t, _ in op.get("out2", [])]
+                        + ([op["chain_out"]] if op.get("chain_out") is not None else [])):
                 pool = free.get(out.elems, [])
                 pick = None
                 for k in range(len(pool) - 1, -1, -1):
@@ -455,6 +480,9 @@ class HRNetProgram:
             o.res_buf = _lib.UDP_BUF_NONE if op["res"] is None else self._phys[op["res"].id]
             for f in ("in_coff", "in_pitch", "out_coff", "out_pitch", "res_coff", "res_pitch", "w2_off", "b2_off", "group", "wfmt", "wexp"):
                 setattr(o, f, op.get(f, 0))
+            if op.get("chain_out") is not None:
+                o.chain_cout, o.chain_relu, o.chain_wexp = op["chain_cout"], op["chain_relu"], op["chain_wexp"]
+                o.chain_buf = self._phys[op["chain_out"].id]
             o.n_out2 = len(op.get("out2", []))
             for k, ((t2, c2), (ta, ca)) in enumerate(zip(op.get("out2", []), op.get("add2", []))):
                 o.out2_buf[k], o.out2_coff[k], o.out2_pitch[k] = self._phys[t2.id], c2, t2.c
@@ -481,6 +509,7 @@ class HRNetProgram:
 
     def macs_per_image(self):
         return sum(op["ks"] ** 2 * op["cin"] * op["cout"] * op["hout"] * op["wout"] * (2 if op["kind"] == _lib.UDP_OP_BLOCK else 1)
+                   + op.get("chain_cout", 0) * op["cout"] * op["hout"] * op["wout"]
                    for op in self._ops
                    if op["kind"] in (_lib.UDP_OP_STEM, _lib.UDP_OP_CONV, _lib.UDP_OP_STEM7, _lib.UDP_OP_BLOCK))
 
@@ -492,4 +521,6 @@ class HRNetProgram:
             if op["res"] is not None:
                 n += op["res"].elems
             n += sum(t.elems for t, _ in op["ups"])
+            if op.get("chain_out") is not None:
+                n += op["chain_out"].elems
         return n
