@@ -237,10 +237,11 @@ __device__ __forceinline__ void conv_ws_body(const ConvParams& p, const int tile
       if (c == 4) UDP_STAMP(13);
       // (at s == 0 the residual loads, issued behind the chunk-0 DMA, may stay in flight as well)
       bool refill = false;
-      if constexpr (STRIDE == 2) refill = p.sbuf && c > 0;
+      if constexpr (STRIDE == 2 || OUT2) refill = p.sbuf && c > 0;   // (not in the merged kernel: its members keep two stages)
       if (refill) {
-        // ONE stage buffer (stride-2 convs with several K chunks: their 4x input tile makes two stage buffers 110 KB,
-        // i.e. one workgroup -- four waves -- per CU; with one buffer two workgroups fit and hide each other's DMA):
+        // ONE stage buffer (convs launched on their own whose two stage buffers exceed half the LDS -- stride-2 convs with
+        // several K chunks: 4x input tile, 110 KB; 3x3 convs on 48-pixel-wide rows of 64+ channels: 128 KB -- i.e. one
+        // workgroup, four waves, per CU; with one buffer two workgroups fit and hide each other's DMA):
         // refill it once every wave has left chunk c - 1, wait for it (the A loads just issued are older), go on
         __syncthreads();
         stage(c, smem);
@@ -259,7 +260,7 @@ __device__ __forceinline__ void conv_ws_body(const ConvParams& p, const int tile
         if (c == 2) UDP_STAMP(12);
         if (c == 4) UDP_STAMP(14);
 #if !(UDP_WS_DBG & 4)
-        if (c + 1 < nchunks && !(STRIDE == 2 && p.sbuf)) stage(c + 1, smem + ((c + 1) & 1) * stage_bytes);
+        if (c + 1 < nchunks && !((STRIDE == 2 || OUT2) && p.sbuf)) stage(c + 1, smem + ((c + 1) & 1) * stage_bytes);
 #endif
         sb = smem + (c & 1) * stage_bytes;
       }
@@ -503,7 +504,7 @@ struct WsTile {
   size_t lds;
 };
 // Tile of a (cout pairs per workgroup, pixel blocks per wave) candidate; false if it cannot be built.
-static bool ws_tile(const ConvParams& p, int ks, int stride, int cp, int pb, WsTile* t) {
+static bool ws_tile(const ConvParams& p, int ks, int stride, int cp, int pb, WsTile* t, bool own_launch) {
   const int pg = 4 / cp;
   const int maxM = 16 * pb * pg;
   // column split: the full width, or 2..4 equal column tiles -- whichever fills the wave's pixel blocks best
@@ -530,9 +531,11 @@ static bool ws_tile(const ConvParams& p, int ks, int stride, int cp, int pb, WsT
     if (npix(G, R) > MAXG * 64) continue;
     int nstage = ceil_div(p.Cin, 32) > 1 ? 2 : 1;                               // stage buffers x (hi, lo) images
     size_t lds = (size_t)((npix(G, R) + 15) / 16) * 16 * ROWB * 2 * nstage;
-    // stride 2: a second workgroup per CU is worth more than the second stage buffer (conv_ws_body, `refill`)
-    static const bool sbuf_ok = getenv("UDP_POSE_WS_SBUF") == nullptr || atoi(getenv("UDP_POSE_WS_SBUF")) != 0;
-    const bool sbuf = stride == 2 && nstage == 2 && lds > 80 * 1024 && lds / 2 <= 80 * 1024 && sbuf_ok;
+    // a second workgroup per CU is worth more than the second stage buffer (conv_ws_body, `refill`; the kernels of convs
+    // launched on their own have it: stride 2, and 3x3 stride 1 outside a launch group).  UDP_POSE_WS_SBUF: 0 off, 2 stride 2 only
+    static const int sbuf_mode = getenv("UDP_POSE_WS_SBUF") == nullptr ? 1 : atoi(getenv("UDP_POSE_WS_SBUF"));
+    const bool sbuf_kernel = stride == 2 || (ks == 3 && own_launch && sbuf_mode != 2);
+    const bool sbuf = sbuf_kernel && nstage == 2 && lds > 80 * 1024 && lds / 2 <= 80 * 1024 && sbuf_mode != 0;
     if (sbuf) {
       nstage = 1;
       lds /= 2;
@@ -588,7 +591,7 @@ int describe_conv_ws(ConvParams p, int ks, int stride, Launch* out, bool grouped
   for (int pb : {6, 4, 3, 2}) {
     for (int cp : {4, 2, 1}) {
       if (pairs % cp || (force_cp && cp != force_cp) || (force_pb && pb != force_pb)) continue;
-      if (!ws_tile(p, ks, stride, cp, pb, &t)) continue;
+      if (!ws_tile(p, ks, stride, cp, pb, &t, !grouped)) continue;
       const bool fills = t.wgs >= min_wgs, best_fills = have && best.wgs >= min_wgs;
       if (!have || (!best_fills && (fills || t.wgs > best.wgs))) {
         best = t;
