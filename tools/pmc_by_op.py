@@ -18,7 +18,7 @@ def rows(d, counter):
     f = (glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"))[0]
     out = []
     for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] == counter and any(k in r["Kernel_Name"] for k in ("conv_mfma_", "conv_ws_", "basic_block_c32", "stem_conv_kernel", "stem_mfma_k", "fuse_sum_kernel")):
+        if r["Counter_Name"] == counter and any(k in r["Kernel_Name"] for k in ("conv_mfma_", "conv_ws_", "conv_chain_", "basic_block_c32", "stem_conv_kernel", "stem_mfma_k", "fuse_sum_kernel")):
             out.append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
     out.sort()
     return [v for _, v in out]
@@ -40,6 +40,8 @@ def main():
     for (name, kind, ks, st, cin, cout, ho, wo), op, f, w in zip(desc, prog._ops, fe, wr):
         key = {0: "stem", 2: "fuse_sum", 10: "basic_block_c32"}.get(kind, "conv%dx%d_s%d_nb%d" % (ks, ks, st, 4 if cout % 64 == 0 else 2))
         alg = (ho * st * wo * st * cin * (4 if kind == 0 else esz) + ho * wo * cout * esz) * b
+        if op.get("chain_out") is not None:      # chained 1x1 conv (udp_conv_op.chain_cout): its output is written too
+            alg += op["chain_out"].elems * esz * b
         extra = ((op["res"].elems if op.get("res") is not None else 0) + sum(t.elems for t, _ in op.get("ups", []))) * esz * b
         c = classes.setdefault(key, dict(launches=0, fetch_bytes=0.0, write_bytes=0.0, algorithmic_in_out_bytes=0.0,
                                          algorithmic_bytes_with_addends=0.0))
