@@ -441,8 +441,12 @@ __global__ __launch_bounds__(256, 2) void conv_ws_h2_kernel(const ConvParams p) 
 
 // Merged launch of up to 4 independent weight-stationary convs (same-depth convs of different HRNet branches):
 // every member runs the 6-pixel-blocks-per-wave body with its own cout-pair split (ConvMulti::code = CP).
+#ifndef UDP_WS_MPB
+#define UDP_WS_MPB 6      // pixel blocks per wave of the merged kernel's members
+#define UDP_WS_MOCC 2     // workgroups per CU the merged kernel is compiled for (waves per SIMD)
+#endif
 template <int KS>
-__global__ __launch_bounds__(256, 2) void conv_ws_multi(const ConvMulti m) {
+__global__ __launch_bounds__(256, UDP_WS_MOCC) void conv_ws_multi(const ConvMulti m) {
   const unsigned b = blockIdx.x;
   int j, tile, cby;
   // (readfirstlane: the dynamically indexed kernel-argument reads are uniform, the compiler does not see it and
@@ -467,9 +471,9 @@ __global__ __launch_bounds__(256, 2) void conv_ws_multi(const ConvMulti m) {
     code = m.code[j];
   }
   switch (code) {
-    case 1: conv_ws_body<KS, 1, 6, 1, false>(m.p[j], tile, (int)cby); break;
-    case 2: conv_ws_body<KS, 1, 6, 2, false>(m.p[j], tile, (int)cby); break;
-    default: conv_ws_body<KS, 1, 6, 4, false>(m.p[j], tile, (int)cby); break;
+    case 1: conv_ws_body<KS, 1, UDP_WS_MPB, 1, false>(m.p[j], tile, (int)cby); break;
+    case 2: conv_ws_body<KS, 1, UDP_WS_MPB, 2, false>(m.p[j], tile, (int)cby); break;
+    default: conv_ws_body<KS, 1, UDP_WS_MPB, 4, false>(m.p[j], tile, (int)cby); break;
   }
 }
 
@@ -591,6 +595,7 @@ int describe_conv_ws(ConvParams p, int ks, int stride, Launch* out, bool grouped
   for (int pb : {6, 4, 3, 2}) {
     for (int cp : {4, 2, 1}) {
       if (pairs % cp || (force_cp && cp != force_cp) || (force_pb && pb != force_pb)) continue;
+      if (grouped && stride == 1 && UDP_WS_MPB != 6 && pb != UDP_WS_MPB) continue;   // (diagnostic builds of the merged kernel)
       if (!ws_tile(p, ks, stride, cp, pb, &t, !grouped)) continue;
       const bool fills = t.wgs >= min_wgs, best_fills = have && best.wgs >= min_wgs;
       if (!have || (!best_fills && (fills || t.wgs > best.wgs))) {
@@ -625,7 +630,7 @@ int describe_conv_ws(ConvParams p, int ks, int stride, Launch* out, bool grouped
   if (rc == 1) return fail(UDP_ERR_UNSUPPORTED, "weight-stationary conv: no kernel for PB=%d CP=%d", best.pb, best.cp);
   if (rc == UDP_OK && p.nout2 && !(ks == 3 && stride == 1))
     return fail(UDP_ERR_UNSUPPORTED, "second outputs: 3x3 stride-1 convs only");
-  if (rc == UDP_OK && grouped && best.pb == 6 && stride == 1 && !p.nout2) {
+  if (rc == UDP_OK && grouped && best.pb == UDP_WS_MPB && stride == 1 && !p.nout2) {
     out->groupable = 300 + ks * 10 + 6;        // storage/kernel family 3 = split fp16 weight-stationary
     out->ws_cp = best.cp;
   }
