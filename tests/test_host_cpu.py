@@ -70,7 +70,18 @@ def test_program_census_matches_survey(dtype, monkeypatch):
     # split fp16: conv3 of layer1.k and conv1 of layer1.k+1 are one chained launch (udp_conv_op.chain_cout), k = 0..2
     chained = sum(1 for o in prog.ops_array() if o.chain_cout)
     assert chained == (3 if dtype == "f16x2" else 0)
-    assert kinds.count(_lib.UDP_OP_STEM) + kinds.count(_lib.UDP_OP_CONV) + 2 * n_block + chained == 293
+    # merged-launch programs (bf16 / split fp16): the stride-2 convs that end the terms of an exchange-unit output i >= 2 are
+    # ONE conv over the concatenated inputs: 4 x (2 -> 1) in stage 3, 2 x ((2 -> 1) + (3 -> 1)) in stage 4
+    fused_terms = 0 if dtype == "f32" else 10
+    assert kinds.count(_lib.UDP_OP_STEM) + kinds.count(_lib.UDP_OP_CONV) + 2 * n_block + chained == 293 - fused_terms
+    monkeypatch.setenv("UDP_POSE_NO_FUSE_CONCAT", "1")
+    per_term = hrnet_plan.HRNetProgram(sd, synth.W32_EXTRA, 256, 192, dtype)
+    monkeypatch.delenv("UDP_POSE_NO_FUSE_CONCAT")
+    assert [d[1] for d in per_term.describe()].count(_lib.UDP_OP_CONV) == kinds.count(_lib.UDP_OP_CONV) + fused_terms
+    assert per_term.macs_per_image() == prog.macs_per_image()
+    if fused_terms:
+        wide = sorted(d[4:6] for d in prog.describe() if d[3] == 2 and d[4] in (96, 224))
+        assert wide == [(96, 128)] * 6 + [(224, 256)] * 2
     assert [d[1] for d in plain.describe()].count(_lib.UDP_OP_CONV) == kinds.count(_lib.UDP_OP_CONV) + 1
     assert plain.macs_per_image() == prog.macs_per_image()
     # the shortcut map is neither written nor read back; a chained conv does not read the 256-channel map again

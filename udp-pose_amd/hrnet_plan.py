@@ -39,6 +39,22 @@ class _T:
         return self.c * self.h * self.w
 
 
+class _V:
+    """Channels [coff, coff + c) of tensor ``t`` (a channel-slice view: udp_conv_op.in_coff / res_coff + pitch)."""
+    __slots__ = ("t", "coff", "c")
+
+    def __init__(self, t, coff, c):
+        self.t, self.coff, self.c = t, coff, c
+
+    @property
+    def h(self):
+        return self.t.h
+
+    @property
+    def w(self):
+        return self.t.w
+
+
 def _round_up(x, m):
     return (x + m - 1) // m * m
 
@@ -80,7 +96,8 @@ class HRNetProgram:
         self.dtype = dtype
         self.in_h, self.in_w = in_h, in_w
         self.fuse_blocks = os.environ.get("UDP_POSE_NO_BLOCK_FUSION") is None
-        self.group_convs = dtype in ("bf16", "f16x2") and os.environ.get("UDP_POSE_NO_GROUPS") is None
+        self.block_major = dtype in ("bf16", "f16x2")       # modules emitted block by block over all branches
+        self.group_convs = self.block_major and os.environ.get("UDP_POSE_NO_GROUPS") is None
         # split-fp16 convs on the weight-stationary kernel (fragment-major weights, udp_conv_op.wfmt = 1)
         # (UDP_POSE_WS=0: the LDS-staged conv_mfma_kernel<H2> instead -- A/B knob)
         self.use_ws = dtype == "f16x2" and os.environ.get("UDP_POSE_WS", "1") != "0"
@@ -116,10 +133,10 @@ class HRNetProgram:
 
     def _pack_conv(self, conv, bn, ws=False, plus=None):
         w, b = self._fold(conv, bn)
-        if plus is not None:                    # conv(x_a) + conv'(x_b) = one conv over [x_a | x_b]
-            w2, b2 = self._fold(*plus)
+        for other in ([plus] if isinstance(plus, tuple) else (plus or [])):      # conv(x_a) + conv'(x_b) = one conv over [x_a | x_b]
+            w2, b2 = self._fold(*other)
             if w2.shape[0] != w.shape[0] or w2.shape[2:] != w.shape[2:]:
-                raise ValueError("%s + %s: different geometry" % (conv, plus[0]))
+                raise ValueError("%s + %s: different geometry" % (conv, other[0]))
             w, b = torch.cat([w, w2], dim=1), b + b2
         cout, cin, kh, kw = w.shape
         cout_pad = _round_up(cout, 32)
@@ -152,6 +169,13 @@ class HRNetProgram:
         applied to this conv's result in the same launch (udp_conv_op.chain_cout) -- returns ``(out, chained out)``."""
         ws = self.use_ws and not to_output and int(self.sd[conv + ".weight"].shape[2]) in (1, 3) and stride in (1, 2)
         w_off, b_off, cout, cin, ks, cout_pad = self._pack_conv(conv, bn, ws, plus)
+        if isinstance(x, _V):                    # ``x`` / ``res`` may be channel-slice views (_V) of wider tensors
+            if cin != x.c:
+                raise ValueError("%s: weight expects %d input channels, view has %d" % (conv, cin, x.c))
+            x, in_coff = x.t, x.coff
+        res_view = res if isinstance(res, _V) else None
+        if res_view is not None:
+            res = res_view.t
         if cin != x.c and in_coff is None:
             raise ValueError("%s: weight expects %d input channels, tensor has %d" % (conv, cin, x.c))
         pad = ks // 2
@@ -165,6 +189,10 @@ class HRNetProgram:
             if in_coff + cin > x.c:
                 raise ValueError("%s: channels %d..%d of a %d-channel tensor" % (conv, in_coff, in_coff + cin, x.c))
             op.update(in_coff=in_coff, in_pitch=x.c)
+        if res_view is not None:
+            if res_view.c != cout or (res.h, res.w) != (ho, wo):
+                raise ValueError("%s: residual view does not match the output" % conv)
+            op.update(res_coff=res_view.coff, res_pitch=res.c, res_c=cout)
         if into:
             if (out.h, out.w) != (ho, wo) or into[1] + cout > out.c:
                 raise ValueError("%s: output slice does not fit its tensor" % conv)
@@ -327,28 +355,45 @@ class HRNetProgram:
     def _module(self, xs, p, num_blocks, last):
         nb = len(xs)
         xs = list(xs)
-        if self.group_convs and len(set(num_blocks[:nb])) == 1:
+        n_out = 1 if last else nb
+        # Exchange-unit output i >= 2 sums stride-2 convs of tensors that all live at resolution level i - 1: the
+        # intermediates of the chains from branches j < i - 1 and the output of branch i - 1 itself (pose_hrnet.py:
+        # 236-255).  Side by side in ONE tensor they are one conv over the concatenated channels (weights side by side,
+        # biases added, one fp32 accumulation): cat[i] = (tensor, channel offset of branch i - 1's output in it); the
+        # branch's last conv2 and the chains' last intermediates write their slices.  (UDP_POSE_NO_FUSE_CONCAT=1: one
+        # conv per term, for A/B)
+        cat = {}
+        if (self.block_major and len(set(num_blocks[:nb])) == 1 and os.environ.get("UDP_POSE_NO_FUSE_CONCAT") is None):
+            for i in range(2, n_out):
+                lead = sum(xs[j].c for j in range(i - 1))
+                if (lead + xs[i - 1].c) % 32 == 0 and lead % 8 == 0:
+                    cat[i] = (self._new(lead + xs[i - 1].c, xs[i - 1].h, xs[i - 1].w), lead)
+        if self.block_major and len(set(num_blocks[:nb])) == 1:
             # block-major order: conv1 of block k of every branch, then conv2 of every branch.  The convs of
             # one such row are independent; those the executor can merge carry a common group id
             for k in range(num_blocks[0]):
                 qs = ["%s.branches.%d.%d" % (p, b, k) for b in range(nb)]
                 plain = [b for b in range(nb) if not self._can_fuse_block(xs[b], qs[b])
                          and (qs[b] + ".deattn.conv_q_right.weight") not in self.sd]
-                gid = (self._next_group(), self._next_group()) if len(plain) > 1 else (0, 0)
+                gid = (self._next_group(), self._next_group()) if self.group_convs and len(plain) > 1 else (0, 0)
                 mids = {}
                 order = list(reversed(plain)) if os.environ.get("UDP_POSE_GROUP_FWD") is None else plain
                 for b in order:            # deepest-K members first: their workgroups run longest
                     mids[b] = self._conv(xs[b], qs[b] + ".conv1", qs[b] + ".bn1", group=gid[0])
+                final = k == num_blocks[0] - 1
                 for b in order:
-                    xs[b] = self._conv(mids[b], qs[b] + ".conv2", qs[b] + ".bn2", res=xs[b], group=gid[1])
+                    dst = cat.get(b + 1) if final else None
+                    y = self._conv(mids[b], qs[b] + ".conv2", qs[b] + ".bn2", res=xs[b], group=gid[1], into=dst)
+                    xs[b] = _V(dst[0], dst[1], xs[b].c) if dst else y
                 for b in range(nb):
                     if b not in plain:
                         xs[b] = self._basic_block(xs[b], qs[b])
+                        if final:
+                            cat.pop(b + 1, None)        # no slice writer for this branch: one conv per term
         else:
             for b in range(nb):
                 for k in range(num_blocks[b]):
                     xs[b] = self._basic_block(xs[b], "%s.branches.%d.%d" % (p, b, k))
-        n_out = 1 if last else nb
         outs = []
         # the 1x1 convs of all j > i terms only read the branch outputs: emitted first, in launch groups of <= 4
         pairs = [(i, j) for i in range(n_out) for j in range(i + 1, nb)]
@@ -373,6 +418,19 @@ class HRNetProgram:
                                           wout=xs[0].w, inp=xs[0], out=out, res=None, ups=ups, w_off=0, b_off=0,
                                           name=p + ".fuse0"))
                     outs.append(out)
+                continue
+            if i in cat:
+                ct, _ = cat[i]
+                off = 0
+                for j in range(i - 1):                  # the chains: their last intermediate lands in its slice of ct
+                    t = xs[j]
+                    for k in range(i - j - 1):
+                        q = "%s.fuse_layers.%d.%d.%d" % (p, i, j, k)
+                        t = self._conv(t, q + ".0", q + ".1", stride=2, into=(ct, off) if k == i - j - 2 else None)
+                    off += xs[j].c
+                names = ["%s.fuse_layers.%d.%d.%d" % (p, i, j, i - j - 1) for j in range(i)]
+                outs.append(self._conv(ct, names[0] + ".0", names[0] + ".1", stride=2, relu=True, res=xs[i], ups=ups,
+                                       plus=[(n + ".0", n + ".1") for n in names[1:]]))
                 continue
             res, t = xs[i], None
             for j in range(i):
@@ -519,7 +577,7 @@ class HRNetProgram:
         for op in self._ops:
             n += op["hin"] * op["win"] * op["cin"] + op["hout"] * op["wout"] * op["cout"]
             if op["res"] is not None:
-                n += op["res"].elems
+                n += op["res"].elems // op["res"].c * op.get("res_c", op["res"].c)
             n += sum(t.elems for t, _ in op["ups"])
             if op.get("chain_out") is not None:
                 n += op["chain_out"].elems
