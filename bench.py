@@ -530,9 +530,11 @@ def main():
             try:
                 cb, x, c, s, ref, ref_hm = cpu_baseline(sd)
                 line["cpu_baseline"] = cb
-                line["parity_vs_cpu_oracle"] = parity(sorted({args.dtype, "f32"} | set(other)), sd, x, c, s, ref, ref_hm, device)
+                modes = sorted({args.dtype, "f32"} | {m for m in other if m in ("f32", "bf16", "f16x2")})
+                line["parity_vs_cpu_oracle"] = parity(modes, sd, x, c, s, ref, ref_hm, device)
             except Exception as e:                                  # noqa: BLE001
                 line.setdefault("cpu_baseline", {"error": "%s: %s" % (type(e).__name__, e)})
+                line.setdefault("parity_vs_cpu_oracle", {"error": "%s: %s" % (type(e).__name__, e)})
         if world == 1 and args.model == "w32" and not args.no_other_configs:
             del hp, net
             torch.cuda.empty_cache()
