@@ -22,6 +22,17 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 // (hi*hi into the main accumulator; hi*lo and lo*hi into a second one that is folded in with 2^-11 at the
 // end; lo*lo ~ 2^-22 is dropped), i.e. fp32-grade results on the 2.5 PF fp16 matrix pipe instead of the
 // 157 TF fp32 one.  Memory layout: per pixel (or weight row) the C hi values, then the C lo values.
+// cache-policy bits (aux operand of the buffer builtins: 1 = sc0, 2 = nt, 16 = sc1) of the split-fp16 activation stores /
+// residual loads / tile DMA -- diagnostic builds only (-DUDP_H2_STORE_AUX=2 ...); 0 = default policy
+#ifndef UDP_H2_STORE_AUX
+#define UDP_H2_STORE_AUX 0
+#endif
+#ifndef UDP_H2_RES_AUX
+#define UDP_H2_RES_AUX 0
+#endif
+#ifndef UDP_H2_DMA_AUX
+#define UDP_H2_DMA_AUX 0
+#endif
 struct H2 {};
 #ifndef UDP_WS_AD
 #define UDP_WS_AD 3     // A-fragment ring depth of the weight-stationary kernels (4 / 5: 245 / 256 registers, -0.6 / -1.5 %)
@@ -201,7 +212,7 @@ __device__ __forceinline__ int fdiv20(int x, unsigned m) { return (int)(__umul24
 // LDS-DMA through a buffer descriptor: SGPR base + 32-bit per-lane offset; lanes whose offset is out
 // of range get ZEROS written to LDS (checked on MI355X: tools/micro/bl_lds.hip) -> conv zero padding
 __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned char* lds_wave_base) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, 0, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, 0, 0, UDP_H2_DMA_AUX);
 }
 
 // 4*NB consecutive channels of one pixel <-> the NB accumulator tiles of a lane, through a buffer
@@ -289,8 +300,8 @@ __device__ __forceinline__ void store_vec_buf(__amdgpu_buffer_rsrc_t r, unsigned
     for (int h = 0; h < NB / 2; ++h) {
       f16x8 hi, lo;
       h2_split8(v[2 * h], v[2 * h + 1], hi, lo);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi), r, voff + 16 * h, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo), r, voff + lo_off + 16 * h, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi), r, voff + 16 * h, 0, UDP_H2_STORE_AUX);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo), r, voff + lo_off + 16 * h, 0, UDP_H2_STORE_AUX);
     }
   } else {
 #pragma unroll

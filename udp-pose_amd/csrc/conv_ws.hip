@@ -27,8 +27,8 @@ template <int NB>
 __device__ __forceinline__ void load_res_h2(ResH2<NB>& o, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned lo_off) {
 #pragma unroll
   for (int h = 0; h < NB / 2; ++h) {
-    o.hi[h] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + 16 * h, 0, 0);
-    o.lo[h] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + lo_off + 16 * h, 0, 0);
+    o.hi[h] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + 16 * h, 0, UDP_H2_RES_AUX);
+    o.lo[h] = __builtin_amdgcn_raw_buffer_load_b128(r, voff + lo_off + 16 * h, 0, UDP_H2_RES_AUX);
   }
 }
 template <int NB>
