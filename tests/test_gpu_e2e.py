@@ -269,6 +269,38 @@ def test_layer1_chained_convs_equal_separate_convs(w32_gaussian, n):
     assert torch.equal(out[True], out[False])
 
 
+@pytest.mark.parametrize("knob,dtype", [("UDP_POSE_NO_L1_CONCAT", "f32"), ("UDP_POSE_NO_L1_CONCAT", "f16x2"),
+                                        ("UDP_POSE_NO_FUSE_CONCAT", "f16x2")])
+def test_convs_over_concatenated_channels_match_one_conv_per_term(w32_gaussian, knob, dtype):
+    """Two planner rewrites sum convs by concatenating their inputs (weights side by side, biases added, ONE fp32
+    accumulation): layer1.0's conv3 + projection shortcut, and the stride-2 convs that end the terms of an exchange-unit
+    output.  Against the program with one conv per term (partial results rounded to storage in between) the heat-maps
+    move by rounding noise only: <= 2e-5 of their scale, arg-max unchanged."""
+    sd, _ = w32_gaussian
+    x = torch.from_numpy(synth.synth_crops(6, 256, 192, seed=29)).cuda()
+    out = {}
+    saved = os.environ.get(knob)
+    try:
+        for per_term in (False, True):
+            os.environ.pop(knob, None)
+            if per_term:
+                os.environ[knob] = "1"
+            net = MODELS["pose_hrnet"](_cfg(synth.W32_EXTRA, 17, "gaussian"), is_train=False, dtype=dtype)
+            net.load_state_dict(sd).to("cuda")
+            out[per_term] = net.raw_forward(x, flip_test=True).clone()
+            n_ops = len(net._compiled[(256, 192)][2].ops_array())
+            out[(per_term, "ops")] = n_ops
+            del net
+    finally:
+        os.environ.pop(knob, None)
+        if saved is not None:
+            os.environ[knob] = saved
+    assert out[(True, "ops")] > out[(False, "ops")]
+    scale = float(out[True].abs().max())
+    assert float((out[False] - out[True]).abs().max()) <= 2e-5 * scale
+    assert torch.equal(out[False].flatten(2).argmax(2), out[True].flatten(2).argmax(2))
+
+
 def test_w32_bf16_mode_accuracy(golden_dir, w32_gaussian):
     """bf16 storage (fp32 accumulate) is REDUCED PRECISION and not a parity mode: this is a sanity bound on what it
     does to the (noise-like) reference heat-maps, far outside the 1e-3 / arg-max contract that the fp32 and
