@@ -146,7 +146,7 @@ typedef struct udp_conv_op {
   int32_t out2_buf[2], out2_coff[2], out2_pitch[2];
   int32_t add2_buf[2], add2_coff[2], add2_pitch[2];
   /* Chained 1x1 conv (udp_hrnet_* programs; chain_cout == 0: none).  A UDP_F16X2 1x1 stride-1 UDP_OP_CONV with wfmt 1,
-   * cin 64 | 128, cout a multiple of 32, a dense-or-sliced NHWC `out`, no up-sampled addends and no second outputs feeds
+   * cin 64 | 128, cout 256, a dense-or-sliced NHWC `out`, no up-sampled addends and no second outputs feeds
    * its result -- the value AS STORED in `out` -- straight into a second 1x1 conv + bias (+ ReLU if chain_relu) of
    * chain_cout (= 64) output channels, written densely to chain_buf: the Bottleneck chain of pose_hrnet.py:80-100
    * (conv3 + bn3 + shortcut + ReLU of one block, conv1 + bn1 + ReLU of the next) in one launch, the 4 * planes-channel

@@ -269,6 +269,42 @@ def test_layer1_chained_convs_equal_separate_convs(w32_gaussian, n):
     assert torch.equal(out[True], out[False])
 
 
+def test_create_rejects_malformed_chained_convs():
+    """udp_hrnet_create checks a chained conv (udp_conv_op.chain_cout) where the program is built, not at the first
+    forward: shape outside what conv_chain_kernel computes, a chained op inside a launch group, an aliased or missing
+    chain buffer, weights outside the blob -- each refused with its own message; the untouched program is accepted."""
+    import ctypes as C
+    from udp_pose_amd import _lib, hrnet_plan
+    extra = synth.scaled_extra(32, modules=(1, 1, 1), blocks=1)
+    sd = synth.synth_state_dict(extra, 17, "gaussian", seed=3)
+    prog = hrnet_plan.HRNetProgram(sd, extra, 64, 64, "f16x2")
+    blob = torch.from_numpy(prog.weight_blob()).cuda()
+    bufs = (C.c_int64 * len(prog.buf_elems))(*prog.buf_elems)
+
+    def create(mutate=None):
+        ops = prog.ops_array()
+        k = [i for i, o in enumerate(ops) if o.chain_cout][0]
+        if mutate:
+            mutate(ops[k])
+        h = C.c_void_p()
+        rc = _lib.lib().udp_hrnet_create(ops, len(ops), bufs, len(prog.buf_elems), _lib.ptr(blob), blob.numel(),
+                                         _lib.DTYPES["f16x2"], 64, 64, prog.out_channels, C.byref(h))
+        if rc == 0:
+            _lib.lib().udp_hrnet_destroy(h)
+        return rc, _lib.lib().udp_last_error().decode()
+
+    assert create()[0] == 0
+    for mutate, text in ((lambda o: setattr(o, "chain_cout", 32), "chained conv needs"),
+                         (lambda o: setattr(o, "group", 7), "chained conv needs"),
+                         (lambda o: setattr(o, "ks", 3), ""),
+                         (lambda o: setattr(o, "chain_buf", o.out_buf), "chain_buf"),
+                         (lambda o: setattr(o, "chain_buf", 10 ** 6), "chain_buf"),
+                         (lambda o: setattr(o, "w2_off", blob.numel() - 64), "chained conv: weight"),
+                         (lambda o: setattr(o, "chain_wexp", 99), "chained conv: weight")):
+        rc, err = create(mutate)
+        assert rc != 0 and text in err, (rc, err)
+
+
 @pytest.mark.parametrize("knob,dtype", [("UDP_POSE_NO_L1_CONCAT", "f32"), ("UDP_POSE_NO_L1_CONCAT", "f16x2"),
                                         ("UDP_POSE_NO_FUSE_CONCAT", "f16x2")])
 def test_convs_over_concatenated_channels_match_one_conv_per_term(w32_gaussian, knob, dtype):

@@ -158,8 +158,8 @@ static int validate_op(const udp_hrnet* h, const udp_conv_op& o, int idx) {
   }
   if (o.chain_cout) {
     if (o.kind != UDP_OP_CONV || o.wfmt != 1 || h->dtype != UDP_F16X2 || o.ks != 1 || o.stride != 1 || o.group || o.n_up || o.n_out2 ||
-        o.out_buf < 0 || (o.cin != 64 && o.cin != 128) || o.cout % 32 || o.cout_pad != o.cout || o.chain_cout != 64)
-      return fail(UDP_ERR_UNSUPPORTED, "op %d: a chained conv needs an ungrouped split-fp16 1x1 conv (wfmt 1), 64 | 128 -> 32k channels, and 64 chained outputs", idx);
+        o.out_buf < 0 || (o.cin != 64 && o.cin != 128) || o.cout != 256 || o.cout_pad != o.cout || o.chain_cout != 64)
+      return fail(UDP_ERR_UNSUPPORTED, "op %d: a chained conv needs an ungrouped split-fp16 1x1 conv (wfmt 1), 64 | 128 -> 256 channels, and 64 chained outputs", idx);
     if (!buf_ok(o.chain_buf, (int64_t)o.hout * o.wout * o.chain_cout) || o.chain_buf == o.out_buf || o.chain_buf == o.in_buf || o.chain_buf == o.res_buf)
       return fail(UDP_ERR_ARG, "op %d: chain_buf %d missing, too small or aliased", idx, o.chain_buf);
     const size_t w2bytes = (size_t)(o.cout / 32) * (o.chain_cout / 32) * 4096;
