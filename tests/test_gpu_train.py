@@ -232,6 +232,34 @@ def test_graphed_train_step_equals_eager_steps():
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
 
 
+def test_exchange_unit_sums_in_one_launch_equal_term_by_term_sums():
+    """The forward of an exchange-unit output y = relu(sum_j term_j) runs as ONE launch (udp_conv2d_fused, UDP_OP_FUSE: the
+    terms are added in the reference's order, pose_hrnet.py:266-272) where it has at most two same-resolution terms and
+    three up-sampled ones, instead of one read-modify-write launch per term.  fp32 tensors: three training steps end with
+    the same loss and the same parameters, bit for bit."""
+    cfg = {"MODEL": {"EXTRA": EXTRA, "NUM_JOINTS": 5, "TARGET_TYPE": "gaussian"}}
+    sd0 = synth.synth_state_dict(EXTRA, 5, "gaussian", seed=3)
+    batches = [make_batch("gaussian", n=6, seed=90 + k) for k in range(3)]
+    outs = []
+    saved = os.environ.get("UDP_POSE_NO_SUM_FUSION")
+    try:
+        for per_term in (True, False):
+            os.environ.pop("UDP_POSE_NO_SUM_FUSION", None)
+            if per_term:
+                os.environ["UDP_POSE_NO_SUM_FUSION"] = "1"
+            tr = HRNetTrainer(cfg, {k: v.clone() for k, v in sd0.items()}, device="cuda", lr=1e-3)
+            assert tr.fuse_sums == (not per_term)
+            losses = [tr.train_step(x.cuda(), tg.cuda(), tw.cuda()).clone() for x, tg, tw in batches]
+            torch.cuda.synchronize()
+            outs.append((np.array([l.cpu().numpy() for l in losses]), tr.flat.cpu().numpy().copy()))
+    finally:
+        os.environ.pop("UDP_POSE_NO_SUM_FUSION", None)
+        if saved is not None:
+            os.environ["UDP_POSE_NO_SUM_FUSION"] = saved
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-12)
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_stride2_input_gradient_reads_the_stuffed_view(dtype):
     """The input gradient of a stride-2 conv is a stride-1 conv over the output gradient on the even grid of a 2x image.

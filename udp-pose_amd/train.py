@@ -136,6 +136,7 @@ class HRNetTrainer:
         self._side = torch.cuda.Stream(device=self.device) if self.overlap_wgrad else None
         self._side_keep, self._side_busy = [], False
         self.fuse_bn_stats = os.environ.get("UDP_POSE_NO_BN_FUSION") is None     # A/B knob
+        self.fuse_sums = os.environ.get("UDP_POSE_NO_SUM_FUSION") is None        # exchange-unit sums: one launch (A/B knob)
         # gradient buckets for the all-reduce (~25 MB each): consecutive parameters of the flat
         # gradient; a bucket is reduced as soon as the backward has written its last gradient, so the exchange
         # of the late layers' gradients runs under the backward of the early ones (DDP's overlap, which the
@@ -515,9 +516,23 @@ class HRNetTrainer:
         L = _lib.lib()
         t0 = terms[0][0]
         y = self._new(t0.n, t0.h << terms[0][1], t0.w << terms[0][1], t0.c)
-        for k, (t, s) in enumerate(terms):
-            _lib.check(L.udp_ew_accumulate(y.buf.data_ptr(), t.buf.data_ptr(), y.n, y.h, y.w, y.ck, s, int(k == 0),
-                                           int(k == len(terms) - 1), self._dt, self._stream()))
+        flat = [t for t, s in terms if s == 0]
+        ups = [(t, s) for t, s in terms if s > 0]
+        if (self.fuse_sums and 1 <= len(flat) <= 2 and len(ups) <= 3 and terms[:len(flat)] == [(t, 0) for t in flat]):
+            # ONE launch: y = relu(t0 [+ t1] + sum_k up(t_k)), added in the reference's order (udp_conv2d_fused, UDP_OP_FUSE);
+            # fp32 tensors: the numbers of the term-by-term launches below, bit for bit
+            op = self._conv_op(1, 1, y.ck, y.ck, y.h, y.w, y.h, y.w)
+            op.kind, op.relu, op.n_up = _lib.UDP_OP_FUSE, 1, len(ups)
+            for k, (t, s) in enumerate(ups):
+                op.up_shift[k] = s
+            up_ptrs = [t.buf.data_ptr() for t, _ in ups] + [None] * (3 - len(ups))
+            _lib.check(L.udp_conv2d_fused(C.byref(op), self._dt, y.n, flat[0].buf.data_ptr(), None, None,
+                                          flat[1].buf.data_ptr() if len(flat) > 1 else None, up_ptrs[0], up_ptrs[1], up_ptrs[2],
+                                          y.buf.data_ptr(), self._stream()))
+        else:
+            for k, (t, s) in enumerate(terms):
+                _lib.check(L.udp_ew_accumulate(y.buf.data_ptr(), t.buf.data_ptr(), y.n, y.h, y.w, y.ck, s, int(k == 0),
+                                               int(k == len(terms) - 1), self._dt, self._stream()))
 
         def backward():
             g = self._like(y)
