@@ -538,10 +538,17 @@ class HRNetTrainer:
             g = self._like(y)
             _lib.check(L.udp_relu_bwd(y.grad.data_ptr(), y.buf.data_ptr(), g.data_ptr(), g.numel(), self._dt,
                                       self._stream()))
+            handed = not self.fuse_sums
             for t, s in terms:
                 if not t.needs_grad:
                     continue
                 have = t.grad is not None
+                if s == 0 and not have and not handed:
+                    # the first same-resolution term without a gradient yet takes g itself instead of a copy of it: every
+                    # other term of this sum reads g inside this function, later writers of t.grad come later on the tape
+                    t.grad = g
+                    handed = True
+                    continue
                 if not have:
                     t.grad = self._like(t)
                 if s == 0:
