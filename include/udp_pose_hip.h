@@ -192,7 +192,10 @@ double udp_hrnet_flops_per_image(const udp_hrnet* h);
  * UDP_OP_FUSE), ks, stride, relu, cin, cout, cout_pad, hin, win, hout, wout, n_up, up_shift;
  * its buffer ids and blob offsets are ignored except out_buf == UDP_BUF_OUTPUT, which selects
  * the NCHW fp32 output form.  in/res/ups/out: NHWC `dtype`; weights [ks*ks][cout_pad][cin]
- * `dtype`; bias fp32 [cout_pad].  Replaces conv+BN(+add)(+ReLU), pose_hrnet.py:43-59. */
+ * `dtype`; bias fp32 [cout_pad].  Replaces conv+BN(+add)(+ReLU), pose_hrnet.py:43-59.
+ * UDP_OP_FUSE: out = act(in [+ res] + sum_k nearest_up(up_k, up_shift[k])), added in that order; up_shift 0 = an addend
+ * of the output's own resolution (the training step's exchange-unit sums, pose_hrnet.py:266-272, have up to four terms);
+ * weights / bias are ignored (may be NULL). */
 int udp_conv2d_fused(const udp_conv_op* op_host, int dtype, int n, const void* in, const void* weights,
                      const float* bias, const void* res, const void* up0, const void* up1,
                      const void* up2, void* out, void* stream);

@@ -750,7 +750,8 @@ static int conv2d_params(const udp_conv_op* o, int dtype, int n, const void* in,
   p.nup = o->n_up;
   for (int u = 0; u < o->n_up; ++u) {
     const int s = o->up_shift[u];
-    if (!ups[u] || s < 1 || s > 5 || (o->hout & ((1 << s) - 1)) || (o->wout & ((1 << s) - 1)))
+    // (UDP_OP_FUSE also takes same-resolution addends, shift 0: the training step's exchange-unit sums have up to four terms)
+    if (!ups[u] || s < (o->kind == UDP_OP_FUSE ? 0 : 1) || s > 5 || (o->hout & ((1 << s) - 1)) || (o->wout & ((1 << s) - 1)))
       return fail(UDP_ERR_ARG, "udp_conv2d_fused: up %d", u);
     p.up[u] = ups[u];
     p.up_shift[u] = s;

@@ -516,18 +516,19 @@ class HRNetTrainer:
         L = _lib.lib()
         t0 = terms[0][0]
         y = self._new(t0.n, t0.h << terms[0][1], t0.w << terms[0][1], t0.c)
-        flat = [t for t, s in terms if s == 0]
-        ups = [(t, s) for t, s in terms if s > 0]
-        if (self.fuse_sums and 1 <= len(flat) <= 2 and len(ups) <= 3 and terms[:len(flat)] == [(t, 0) for t in flat]):
-            # ONE launch: y = relu(t0 [+ t1] + sum_k up(t_k)), added in the reference's order (udp_conv2d_fused, UDP_OP_FUSE);
-            # fp32 tensors: the numbers of the term-by-term launches below, bit for bit
+        # ONE launch: y = relu(((t0 + t1) + t2) + ...), the terms added in the reference's order (udp_conv2d_fused, UDP_OP_FUSE:
+        # in + res + up to three addends, each up-sampled by its shift; shift 0 = same resolution); fp32 tensors: the numbers of
+        # the term-by-term launches below, bit for bit
+        second = len(terms) > 1 and terms[1][1] == 0           # `res` carries no shift
+        rest = terms[2:] if second else terms[1:]
+        if self.fuse_sums and terms[0][1] == 0 and len(rest) <= 3:
             op = self._conv_op(1, 1, y.ck, y.ck, y.h, y.w, y.h, y.w)
-            op.kind, op.relu, op.n_up = _lib.UDP_OP_FUSE, 1, len(ups)
-            for k, (t, s) in enumerate(ups):
+            op.kind, op.relu, op.n_up = _lib.UDP_OP_FUSE, 1, len(rest)
+            for k, (t, s) in enumerate(rest):
                 op.up_shift[k] = s
-            up_ptrs = [t.buf.data_ptr() for t, _ in ups] + [None] * (3 - len(ups))
-            _lib.check(L.udp_conv2d_fused(C.byref(op), self._dt, y.n, flat[0].buf.data_ptr(), None, None,
-                                          flat[1].buf.data_ptr() if len(flat) > 1 else None, up_ptrs[0], up_ptrs[1], up_ptrs[2],
+            up_ptrs = [t.buf.data_ptr() for t, _ in rest] + [None] * (3 - len(rest))
+            _lib.check(L.udp_conv2d_fused(C.byref(op), self._dt, y.n, terms[0][0].buf.data_ptr(), None, None,
+                                          terms[1][0].buf.data_ptr() if second else None, up_ptrs[0], up_ptrs[1], up_ptrs[2],
                                           y.buf.data_ptr(), self._stream()))
         else:
             for k, (t, s) in enumerate(terms):
