@@ -366,7 +366,7 @@ class HRNetProgram:
         if (self.block_major and len(set(num_blocks[:nb])) == 1 and os.environ.get("UDP_POSE_NO_FUSE_CONCAT") is None):
             for i in range(2, n_out):
                 lead = sum(xs[j].c for j in range(i - 1))
-                if (lead + xs[i - 1].c) % 32 == 0 and lead % 8 == 0:
+                if (lead + xs[i - 1].c) % 8 == 0 and lead % 8 == 0:          # 16-byte aligned slices in both planes
                     cat[i] = (self._new(lead + xs[i - 1].c, xs[i - 1].h, xs[i - 1].w), lead)
         if self.block_major and len(set(num_blocks[:nb])) == 1:
             # block-major order: conv1 of block k of every branch, then conv2 of every branch.  The convs of
