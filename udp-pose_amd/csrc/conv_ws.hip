@@ -575,7 +575,7 @@ static long g_ws_fill_wgs = 512;
 void ws_set_fill_wgs(long wgs) { g_ws_fill_wgs = wgs; }
 
 int describe_conv_ws(ConvParams p, int ks, int stride, Launch* out, bool grouped) {
-  if ((stride != 1 && stride != 2) || (ks != 3 && ks != 1) || p.out_nchw_f32)
+  if ((stride != 1 && stride != 2) || (ks != 3 && ks != 1) || (p.out_nchw_f32 && !(ks == 3 && stride == 1)))
     return fail(UDP_ERR_UNSUPPORTED, "fragment-major weights (wfmt 1): conv ks=%d stride=%d nchw_out=%d has no weight-stationary kernel",
                 ks, stride, p.out_nchw_f32);
   auto knob = [](const char* name, long dflt) {
@@ -596,7 +596,7 @@ int describe_conv_ws(ConvParams p, int ks, int stride, Launch* out, bool grouped
     for (int cp : {4, 2, 1}) {
       if (pairs % cp || (force_cp && cp != force_cp) || (force_pb && pb != force_pb)) continue;
       if (grouped && stride == 1 && UDP_WS_MPB != 6 && pb != UDP_WS_MPB) continue;   // (diagnostic builds of the merged kernel)
-      if (!ws_tile(p, ks, stride, cp, pb, &t, !grouped)) continue;
+      if (!ws_tile(p, ks, stride, cp, pb, &t, !grouped && !p.out_nchw_f32)) continue;   // (the NCHW-output kernels keep two stage buffers)
       const bool fills = t.wgs >= min_wgs, best_fills = have && best.wgs >= min_wgs;
       if (!have || (!best_fills && (fills || t.wgs > best.wgs))) {
         best = t;
@@ -623,7 +623,8 @@ int describe_conv_ws(ConvParams p, int ks, int stride, Launch* out, bool grouped
     fprintf(stderr, "ws conv k%d s%d %dx%d C%d->%d: G=%d R=%d TW=%d CP=%d PB=%d lds=%zu%s wgs=%d\n", ks, stride, p.Hout, p.Wout, p.Cin,
             p.Cout, p.G, p.R, p.TW, best.cp, best.pb, best.lds, best.sbuf ? " (one stage buffer)" : "", best.wgs);
   int rc = 1;
-  if (ks == 3 && stride == 1) rc = describe_ws_pb<3, 1, false>(p, best.pb, best.cp, best.lds, out);
+  if (ks == 3 && stride == 1 && !p.out_nchw_f32) rc = describe_ws_pb<3, 1, false>(p, best.pb, best.cp, best.lds, out);
+  if (ks == 3 && stride == 1 && p.out_nchw_f32) rc = describe_ws_pb<3, 1, true>(p, best.pb, best.cp, best.lds, out);   // the net's NCHW fp32 output (RSN head)
   if (ks == 3 && stride == 2) rc = describe_ws_pb<3, 2, false>(p, best.pb, best.cp, best.lds, out);
   if (ks == 1 && stride == 1) rc = describe_ws_pb<1, 1, false>(p, best.pb, best.cp, best.lds, out);
   if (ks == 1 && stride == 2) rc = describe_ws_pb<1, 2, false>(p, best.pb, best.cp, best.lds, out);
