@@ -575,7 +575,7 @@ static long g_ws_fill_wgs = 512;
 void ws_set_fill_wgs(long wgs) { g_ws_fill_wgs = wgs; }
 
 int describe_conv_ws(ConvParams p, int ks, int stride, Launch* out, bool grouped) {
-  if ((stride != 1 && stride != 2) || (ks != 3 && ks != 1) || (p.out_nchw_f32 && !(ks == 3 && stride == 1)))
+  if ((stride != 1 && stride != 2) || (ks != 3 && ks != 1) || (p.out_nchw_f32 && stride != 1))
     return fail(UDP_ERR_UNSUPPORTED, "fragment-major weights (wfmt 1): conv ks=%d stride=%d nchw_out=%d has no weight-stationary kernel",
                 ks, stride, p.out_nchw_f32);
   auto knob = [](const char* name, long dflt) {
@@ -626,7 +626,8 @@ int describe_conv_ws(ConvParams p, int ks, int stride, Launch* out, bool grouped
   if (ks == 3 && stride == 1 && !p.out_nchw_f32) rc = describe_ws_pb<3, 1, false>(p, best.pb, best.cp, best.lds, out);
   if (ks == 3 && stride == 1 && p.out_nchw_f32) rc = describe_ws_pb<3, 1, true>(p, best.pb, best.cp, best.lds, out);   // the net's NCHW fp32 output (RSN head)
   if (ks == 3 && stride == 2) rc = describe_ws_pb<3, 2, false>(p, best.pb, best.cp, best.lds, out);
-  if (ks == 1 && stride == 1) rc = describe_ws_pb<1, 1, false>(p, best.pb, best.cp, best.lds, out);
+  if (ks == 1 && stride == 1 && !p.out_nchw_f32) rc = describe_ws_pb<1, 1, false>(p, best.pb, best.cp, best.lds, out);
+  if (ks == 1 && stride == 1 && p.out_nchw_f32) rc = describe_ws_pb<1, 1, true>(p, best.pb, best.cp, best.lds, out);   // (HRNet final_layer)
   if (ks == 1 && stride == 2) rc = describe_ws_pb<1, 2, false>(p, best.pb, best.cp, best.lds, out);
   if (rc == 1) return fail(UDP_ERR_UNSUPPORTED, "weight-stationary conv: no kernel for PB=%d CP=%d", best.pb, best.cp);
   if (rc == UDP_OK && p.nout2 && !(ks == 3 && stride == 1))

@@ -167,7 +167,9 @@ class HRNetProgram:
         channels FOLLOW this conv's in ``x`` and whose result is summed in -- one conv over the concatenated channels
         with the weights side by side and the biases added; ``chain = (conv'', bn'')``: a 1x1 conv + BatchNorm + ReLU
         applied to this conv's result in the same launch (udp_conv_op.chain_cout) -- returns ``(out, chained out)``."""
-        ws = self.use_ws and not to_output and int(self.sd[conv + ".weight"].shape[2]) in (1, 3) and stride in (1, 2)
+        # (the output conv writes NCHW fp32 from the weight-stationary kernel too; UDP_POSE_HEAD_WS=0: the LDS-staged kernel)
+        head_ws = to_output and stride == 1 and os.environ.get("UDP_POSE_HEAD_WS", "1") != "0"
+        ws = self.use_ws and (not to_output or head_ws) and int(self.sd[conv + ".weight"].shape[2]) in (1, 3) and stride in (1, 2)
         w_off, b_off, cout, cin, ks, cout_pad = self._pack_conv(conv, bn, ws, plus)
         if isinstance(x, _V):                    # ``x`` / ``res`` may be channel-slice views (_V) of wider tensors
             if cin != x.c:

@@ -86,8 +86,8 @@ class RSNProgram(HRNetProgram):
         the plain output, only the sums are stored."""
         w, b = self._fold_cbr(name)
         # split-fp16 3x3 / 1x1 convs on the weight-stationary kernels (UDP_POSE_RSN_WS=0: the LDS-staged kernel, A/B)
-        # (the 3x3 head conv writes the NCHW fp32 output from the weight-stationary kernel too; UDP_POSE_RSN_HEAD_WS=0: LDS-staged)
-        head_ws = to_output and int(w.shape[2]) == 3 and stride == 1 and os.environ.get("UDP_POSE_RSN_HEAD_WS", "1") != "0"
+        # (the 3x3 head conv writes the NCHW fp32 output from the weight-stationary kernel too; UDP_POSE_HEAD_WS=0: LDS-staged)
+        head_ws = to_output and stride == 1 and os.environ.get("UDP_POSE_HEAD_WS", "1") != "0"
         ws = (self.use_ws and (not to_output or head_ws) and int(w.shape[2]) in (1, 3) and stride in (1, 2)
               and os.environ.get("UDP_POSE_RSN_WS", "1") != "0")
         w_off, b_off, cout, cin, k, cout_pad = self._pack(w, b, out_map, in_map, cout_t, cin_t, ws=ws)
